@@ -1,0 +1,207 @@
+"""numpy wrappers over oracle/liboracle.so (the plain-C restatement in oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never
+by detectorch_amd/.  Function names mirror the reference functions they restate (see oracle.c for file:line).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(HERE, "liboracle.so")
+    src = os.path.join(HERE, "oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        p, i, f, d = C.c_void_p, C.c_int, C.c_float, C.c_double
+        _LIB.orc_roi_align_forward.argtypes = [p, p, i, i, f, i, i, i, i, i, i, p]
+        _LIB.orc_roi_align_forward.restype = None
+        _LIB.orc_generate_anchors.argtypes = [d, p, i, p, i, p]
+        _LIB.orc_generate_anchors.restype = None
+        _LIB.orc_bbox_transform.argtypes = [p, p, i, i, f, f, f, f, p]
+        _LIB.orc_bbox_transform.restype = None
+        _LIB.orc_clip_tiled_boxes.argtypes = [p, i, f, f]
+        _LIB.orc_clip_tiled_boxes.restype = None
+        _LIB.orc_nms.argtypes = [p, i, f, i, p]
+        _LIB.orc_nms.restype = i
+        _LIB.orc_soft_nms.argtypes = [p, i, f, f, f, C.c_uint, p]
+        _LIB.orc_soft_nms.restype = i
+        _LIB.orc_generate_proposals.argtypes = [p, p, i, i, i, p, d, f, f, f, i, i, f, p, p, p, p, p]
+        _LIB.orc_generate_proposals.restype = i
+        _LIB.orc_map_rois_to_fpn_levels.argtypes = [p, i, i, i, p]
+        _LIB.orc_map_rois_to_fpn_levels.restype = None
+        _LIB.orc_collect.argtypes = [p, p, i, i, p, p, p]
+        _LIB.orc_collect.restype = i
+        _LIB.orc_distribute.argtypes = [p, i, i, i, p, p, p]
+        _LIB.orc_distribute.restype = None
+        _LIB.orc_postprocess_detections.argtypes = [p, i, f, p, p, i, f, f, f, f, f, f, f, f, i, p, p]
+        _LIB.orc_postprocess_detections.restype = i
+        _LIB.orc_expand_box_int.argtypes = [p, i, p]
+        _LIB.orc_expand_box_int.restype = None
+        _LIB.orc_mask_resize_binarize.argtypes = [p, i, p, f, p, p]
+        _LIB.orc_mask_resize_binarize.restype = i
+    return _LIB
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def roi_align_forward(features, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio):
+    features, rois = _f32(features), _f32(rois)
+    _, Cn, H, W = features.shape
+    R, cols = rois.shape if rois.size else (0, 5)
+    out = np.zeros((R, Cn, pooled_h, pooled_w), dtype=np.float32)
+    lib().orc_roi_align_forward(features.ctypes.data, rois.ctypes.data, R, cols, spatial_scale, Cn, H, W, pooled_h,
+                                pooled_w, sampling_ratio, out.ctypes.data)
+    return out
+
+
+def generate_anchors(stride=16, sizes=(32, 64, 128, 256, 512), aspect_ratios=(0.5, 1, 2)):
+    s = np.asarray(sizes, dtype=np.float64)
+    r = np.asarray(aspect_ratios, dtype=np.float64)
+    out = np.zeros((len(r) * len(s), 4), dtype=np.float64)
+    lib().orc_generate_anchors(float(stride), s.ctypes.data, len(s), r.ctypes.data, len(r), out.ctypes.data)
+    return out
+
+
+def bbox_transform(boxes, deltas, weights=(1.0, 1.0, 1.0, 1.0)):
+    boxes, deltas = _f32(boxes), _f32(deltas)
+    n = boxes.shape[0]
+    ncls = deltas.shape[1] // 4
+    out = np.zeros_like(deltas)
+    lib().orc_bbox_transform(boxes.ctypes.data, deltas.ctypes.data, n, ncls, *[float(w) for w in weights],
+                             out.ctypes.data)
+    return out
+
+
+def clip_tiled_boxes(boxes, im_h, im_w):
+    boxes = _f32(boxes).copy()
+    lib().orc_clip_tiled_boxes(boxes.ctypes.data, boxes.size // 4, float(im_h), float(im_w))
+    return boxes
+
+
+def nms(dets, thresh, max_keep=0):
+    dets = _f32(dets)
+    n = dets.shape[0]
+    keep = np.zeros(max(n, 1), dtype=np.int64)
+    k = lib().orc_nms(dets.ctypes.data, n, float(np.float32(thresh)), int(max_keep), keep.ctypes.data)
+    return keep[:k].copy()
+
+
+def soft_nms(dets, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, method="linear"):
+    methods = {"hard": 0, "linear": 1, "gaussian": 2}
+    boxes = _f32(dets).copy()
+    n = boxes.shape[0]
+    inds = np.zeros(max(n, 1), dtype=np.int64)
+    k = lib().orc_soft_nms(boxes.ctypes.data, n, float(np.float32(sigma)), float(np.float32(overlap_thresh)),
+                           float(np.float32(score_thresh)), methods[method], inds.ctypes.data)
+    return boxes[:k].copy(), inds[:k].copy()
+
+
+def generate_proposals(scores, deltas, anchors, feat_stride, im_h, im_w, pre_nms_top_n, post_nms_top_n, nms_thresh,
+                       min_size_scaled=0.0, return_pre_nms=False):
+    """scores [A,H,W], deltas [4A,H,W] -> (boxes [k,4], scores [k])."""
+    scores, deltas = _f32(scores), _f32(deltas)
+    anchors = np.ascontiguousarray(anchors, dtype=np.float64)
+    A, H, W = scores.shape
+    N = A * H * W
+    K = N if (pre_nms_top_n <= 0 or pre_nms_top_n >= N) else pre_nms_top_n
+    cap = max(K if (post_nms_top_n <= 0 or nms_thresh <= 0) else min(K, post_nms_top_n), 1)
+    ob = np.zeros((cap, 4), np.float32)
+    os_ = np.zeros((cap,), np.float32)
+    pb = np.zeros((K, 4), np.float32)
+    ps = np.zeros((K,), np.float32)
+    pn = C.c_int(0)
+    k = lib().orc_generate_proposals(scores.ctypes.data, deltas.ctypes.data, A, H, W, anchors.ctypes.data,
+                                     float(feat_stride), float(im_h), float(im_w), float(min_size_scaled),
+                                     int(pre_nms_top_n), int(post_nms_top_n), float(np.float32(nms_thresh)),
+                                     ob.ctypes.data, os_.ctypes.data, pb.ctypes.data, ps.ctypes.data, C.byref(pn))
+    if return_pre_nms:
+        return ob[:k].copy(), os_[:k].copy(), pb[:pn.value].copy(), ps[:pn.value].copy()
+    return ob[:k].copy(), os_[:k].copy()
+
+
+def map_rois_to_fpn_levels(rois, k_min, k_max):
+    rois = _f32(rois)
+    n = rois.shape[0]
+    lv = np.zeros(max(n, 1), np.int32)
+    lib().orc_map_rois_to_fpn_levels(rois.ctypes.data, n, k_min, k_max, lv.ctypes.data)
+    return lv[:n].copy()
+
+
+def collect(rois_cat, scores_cat, post_nms_topN):
+    rois_cat, scores_cat = _f32(rois_cat), _f32(scores_cat).reshape(-1)
+    n = rois_cat.shape[0]
+    m = min(n, post_nms_topN)
+    out = np.zeros((max(m, 1), 4), np.float32)
+    osc = np.zeros(max(m, 1), np.float32)
+    src = np.zeros(max(m, 1), np.int64)
+    k = lib().orc_collect(rois_cat.ctypes.data, scores_cat.ctypes.data, n, post_nms_topN, out.ctypes.data,
+                          osc.ctypes.data, src.ctypes.data)
+    return out[:k].copy(), osc[:k].copy(), src[:k].copy()
+
+
+def distribute(rois, k_min, k_max):
+    """-> (list of per-level roi arrays, idx_restore, lvls)"""
+    rois = _f32(rois)
+    n = rois.shape[0]
+    lv = map_rois_to_fpn_levels(rois, k_min, k_max)
+    counts = np.zeros(k_max - k_min + 1, np.int32)
+    order = np.zeros(max(n, 1), np.int64)
+    restore = np.zeros(max(n, 1), np.int64)
+    lib().orc_distribute(lv.ctypes.data, n, k_min, k_max, counts.ctypes.data, order.ctypes.data, restore.ctypes.data)
+    outs, p = [], 0
+    for c in counts:
+        outs.append(rois[order[p:p + c]])
+        p += c
+    return outs, restore[:n].copy(), lv
+
+
+def postprocess_detections(rois, scaling_factor, im_size, cls_scores, bbox_deltas, weights=(10.0, 10.0, 5.0, 5.0),
+                           score_thresh=0.05, nms_thresh=0.5, max_det=100):
+    """-> (dets [D,6] (x1,y1,x2,y2,score,class), roi_index [D])"""
+    rois, cls_scores, bbox_deltas = _f32(rois), _f32(cls_scores), _f32(bbox_deltas)
+    R, ncls = cls_scores.shape
+    cap = max(R * (ncls - 1), 1)
+    dets = np.zeros((cap, 6), np.float32)
+    src = np.zeros(cap, np.int32)
+    D = lib().orc_postprocess_detections(rois.ctypes.data, R, float(np.float32(scaling_factor)),
+                                         cls_scores.ctypes.data, bbox_deltas.ctypes.data, ncls, float(im_size[0]),
+                                         float(im_size[1]), *[float(w) for w in weights],
+                                         float(np.float32(score_thresh)), float(np.float32(nms_thresh)), int(max_det),
+                                         dets.ctypes.data, src.ctypes.data)
+    return dets[:D].copy(), src[:D].copy()
+
+
+def expand_box_int(ref_box, M):
+    ref_box = _f32(ref_box)
+    out = np.zeros(4, np.int32)
+    lib().orc_expand_box_int(ref_box.ctypes.data, int(M), out.ctypes.data)
+    return out
+
+
+def mask_resize_binarize(mask, ref_box, thresh=0.5):
+    """mask [M,M] -> (box int32[4], crop uint8 [h,w])"""
+    mask, ref_box = _f32(mask), _f32(ref_box)
+    M = mask.shape[0]
+    box = np.zeros(4, np.int32)
+    n = lib().orc_mask_resize_binarize(mask.ctypes.data, M, ref_box.ctypes.data, float(np.float32(thresh)),
+                                       box.ctypes.data, None)
+    crop = np.zeros(n, np.uint8)
+    lib().orc_mask_resize_binarize(mask.ctypes.data, M, ref_box.ctypes.data, float(np.float32(thresh)),
+                                   box.ctypes.data, crop.ctypes.data)
+    w, h = max(box[2] - box[0] + 1, 1), max(box[3] - box[1] + 1, 1)
+    return box, crop.reshape(h, w)

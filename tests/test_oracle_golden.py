@@ -1,0 +1,124 @@
+"""Pin oracle/oracle.c against the golden vectors generated from the reference itself (tests/golden/make_golden.py).
+
+CPU only.  Integer/index results (NMS keep, level ids, restore permutations, class ids) must match bit-for-bit; box
+coordinates that went through exp() must match within 1e-4 (or 1 ulp above 1024): the reference's exp is torch-CPU /
+numpy SIMD, ours is correctly rounded, so the last bit can differ.  RoIAlign must be bit-exact (no transcendental).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, ulp_close
+
+
+def test_anchors_known_answer(oracle):
+    # generate_anchors.py:26-51 documents the 9-anchor table for stride 16, scales 8/16/32 in 1-based (matlab) pixel
+    # coordinates; the Python (0-based) result is that table minus 1.
+    table = np.array([[-83, -39, 100, 56], [-175, -87, 192, 104], [-359, -183, 376, 200], [-55, -55, 72, 72],
+                      [-119, -119, 136, 136], [-247, -247, 264, 264], [-35, -79, 52, 96], [-79, -167, 96, 184],
+                      [-167, -343, 184, 360]], np.float64)
+    got = oracle.generate_anchors(16, (128, 256, 512), (0.5, 1, 2))
+    assert np.array_equal(got, table - 1.0)
+
+
+def test_anchors_golden(oracle):
+    g = golden("anchors")
+    k = 0
+    while "in%d" % k in g:
+        spec = list(g["in%d" % k])
+        sep = spec.index(-1.0)
+        got = oracle.generate_anchors(spec[0], spec[1:sep], spec[sep + 1:])
+        assert np.array_equal(got, g["out%d" % k]), k
+        k += 1
+    assert k == 7
+
+
+@pytest.mark.parametrize("tag", ["p7s2", "p14s0", "p7s0", "p14s2", "p3x5s3"])
+def test_roi_align_golden_bit_exact(oracle, tag):
+    g = golden("roi_align")
+    ph, pw, sr, scale = g["cfg_" + tag]
+    got = oracle.roi_align_forward(g["features"], g["rois5"], int(ph), int(pw), float(scale), int(sr))
+    assert np.array_equal(got, g["out_" + tag])
+
+
+def test_roi_align_golden_4col(oracle):
+    g = golden("roi_align")
+    got = oracle.roi_align_forward(g["features"][:1], g["rois5"][:, 1:], 7, 7, 1 / 16., 2)
+    assert np.array_equal(got, g["out4col_p7s2"])
+
+
+@pytest.mark.parametrize("t", [0.3, 0.5, 0.7])
+def test_nms_golden(oracle, t):
+    g = golden("nms")
+    assert np.array_equal(oracle.nms(g["dets"], t), g["keep_%02d" % int(t * 10)])
+
+
+@pytest.mark.parametrize("method,tag,ot,st", [("hard", "hard", 0.3, 0.001), ("linear", "linear", 0.3, 0.001),
+                                               ("gaussian", "gaussian", 0.3, 0.001), ("linear", "linear05", 0.5, 0.0001)])
+def test_soft_nms_golden(oracle, method, tag, ot, st):
+    g = golden("nms")
+    d, k = oracle.soft_nms(g["dets"], 0.5, ot, st, method)
+    assert np.array_equal(k, g["soft_%s_keep" % tag])
+    assert np.array_equal(d, g["soft_%s_dets" % tag])
+
+
+@pytest.mark.parametrize("tag", ["c4", "p3", "p6"])
+def test_generate_proposals_golden(oracle, tag):
+    g = golden("generate_proposals")
+    cfg = g[tag + "_cfg"]
+    A, H, W = int(cfg[0]), int(cfg[1]), int(cfg[2])
+    ss, pre, post, im_h, im_w, thr = cfg[3], int(cfg[4]), int(cfg[5]), cfg[6], cfg[7], cfg[8]
+    sizes = tuple(cfg[9:])
+    anchors = oracle.generate_anchors(1.0 / ss, sizes, (0.5, 1, 2))
+    props, scores = oracle.generate_proposals(g[tag + "_cls"][0], g[tag + "_bbox"][0], anchors, 1.0 / ss, im_h, im_w,
+                                              pre, post, thr)
+    ref_p, ref_s = g[tag + "_props"], g[tag + "_scores"].reshape(-1)
+    assert props.shape == ref_p.shape
+    assert np.array_equal(scores, ref_s)              # same survivors in the same order (scores are unique keys)
+    assert ulp_close(props, ref_p)
+
+
+def test_collect_distribute_golden(oracle):
+    g = golden("collect_distribute")
+    for pre in ("", "big_"):
+        rois = np.concatenate([g[pre + "rois%d" % l] for l in range(5)])
+        sc = np.concatenate([g[pre + "scores%d" % l] for l in range(5)])
+        top, _, _ = oracle.collect(rois, sc, 1000)
+        outs, restore, _ = oracle.distribute(top, 2, 5)
+        for i in range(4):
+            assert np.array_equal(outs[i], g[pre + "distr%d" % i]), (pre, i)
+        assert np.array_equal(restore, g[pre + "restore"])
+
+
+def test_fpn_level_boundaries_golden(oracle):
+    g = golden("collect_distribute")
+    assert np.array_equal(oracle.map_rois_to_fpn_levels(g["lvl_boxes"], 2, 5), g["lvl_out"])
+
+
+def test_bbox_transform_and_clip_golden(oracle):
+    g = golden("postprocess")
+    boxes = g["rois"] / g["sf"][0]
+    pred = oracle.bbox_transform(boxes, g["deltas"], (10.0, 10.0, 5.0, 5.0))
+    assert ulp_close(pred, g["pred"])
+    assert ulp_close(oracle.clip_tiled_boxes(pred, g["im_size"][0], g["im_size"][1]), g["pred_clipped"])
+
+
+@pytest.mark.parametrize("limit", [100, 0])
+def test_postprocess_golden(oracle, limit):
+    g = golden("postprocess")
+    dets, _ = oracle.postprocess_detections(g["rois"], g["sf"][0], g["im_size"], g["cls"], g["deltas"], max_det=limit)
+    pre = "" if limit else "nolimit_"
+    ref_scores = g["scores_final"] if limit else g["nolimit_scores"]
+    ref_boxes = g["boxes_final"] if limit else g["nolimit_boxes"]
+    assert dets.shape[0] == ref_scores.shape[0]
+    if limit:
+        assert dets.shape[0] >= 100          # the limiting branch really ran
+    assert np.array_equal(dets[:, 4], ref_scores)
+    assert np.array_equal(dets[:, 5].astype(np.int32), g[pre + "cls_id"])
+    assert ulp_close(dets[:, :4], ref_boxes)
+
+
+@pytest.mark.parametrize("M", [14, 28])
+def test_mask_box_geometry_golden(oracle, M):
+    g = golden("mask_geometry")
+    got = np.stack([oracle.expand_box_int(b, M) for b in g["ref_boxes"]])
+    assert np.array_equal(got, g["exp_int_M%d" % M])
