@@ -1,0 +1,41 @@
+// Shared device/host helpers for libdetectorch_hip (gfx950 only; wave = 64 lanes).
+//
+// Numerics contract: the whole library is compiled with -ffp-contract=off.  The reference's float32 results are the
+// product of one rounding per operation in a fixed order (x86 SSE, no FMA), and NMS keep-indices are chaotic in the last
+// bit, so nothing here may be contracted into v_fma/v_mad or re-associated.  Division and sqrt use the IEEE-correct
+// intrinsics explicitly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/detectorch_hip.h"
+
+#define DTC_WAVE 64
+#define DTC_API extern "C" __attribute__((visibility("default")))
+
+#define DTC_CHECK_LAUNCH()                                 \
+  do {                                                     \
+    hipError_t e__ = hipGetLastError();                    \
+    if (e__ != hipSuccess) return DTC_ELAUNCH;             \
+  } while (0)
+
+namespace dtc {
+
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ float fsqrt(float a) { return __fsqrt_rn(a); }
+// exp / log2 evaluated in double and rounded once: correctly-rounded float32 in all but ~1e-8 of inputs, which is what
+// oracle/oracle.c does too (see its header), so HIP == oracle bit-for-bit.
+__device__ __forceinline__ float fexp_cr(float x) { return (float)exp((double)x); }
+__device__ __forceinline__ float flog2_cr(float x) { return (float)log2((double)x); }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half_rn(v); }
+
+__host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace dtc

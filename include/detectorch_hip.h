@@ -1,0 +1,68 @@
+/*
+ * detectorch_hip.h -- C ABI of libdetectorch_hip.so: the MI355X (gfx950 / CDNA4) region-proposal hot path of detectorch.
+ *
+ * Plain pointers and sizes only; no torch / ATen / TH types cross this boundary.  Every entry point
+ *   - takes DEVICE pointers (caller-owned; nothing is allocated or freed inside),
+ *   - enqueues its kernels on the given hipStream_t and returns without synchronising,
+ *   - returns DTC_OK (0) or a negative DTC_E* code (no exceptions, no printf), except the one entry that keeps the
+ *     reference's own 1/0 convention (launch_roi_align_forward_hip).
+ * Workspace is passed in by the caller; dtc_*_workspace_bytes() say how much.
+ *
+ * Each entry cites the reference interface it replaces (paths relative to the detectorch tree).
+ */
+#ifndef DETECTORCH_HIP_H_
+#define DETECTORCH_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* dtc_stream_t; /* == hipStream_t */
+
+enum { DTC_OK = 0, DTC_EINVAL = -1, DTC_ELAUNCH = -2, DTC_EWORKSPACE = -3, DTC_EUNSUPPORTED = -4 };
+enum { DTC_F32 = 0, DTC_F16 = 1 };
+
+/* Library / build identification ("gfx950"); lets the host prove the native path is the one that is loaded. */
+const char* dtc_version(void);
+const char* dtc_target_arch(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * A1  RoIAlign forward
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* Drop-in for  int launch_roi_align_forward_cuda(...)  lib/cppcuda_cffi/src/cuda/roi_align_forward_cuda_kernel.h:7-19
+ * (same argument list, cudaStream_t -> hipStream_t; returns 1 on success, 0 on error like the reference's launcher,
+ * roi_align_forward_cuda_kernel.cu:161-201).  bottom_data float32 NCHW contiguous [B,C,H,W]; bottom_rois float32
+ * [R,5] = (batch_idx, x1, y1, x2, y2); top_data float32 [R,C,PH,PW], R = outputElements / (C*PH*PW). */
+int launch_roi_align_forward_hip(const int outputElements, const float* bottom_data, const float* bottom_rois,
+                                 const float spatial_scale, const int channels, const int height, const int width,
+                                 const int pooled_height, const int pooled_width, const int sampling_ratio,
+                                 float* top_data, dtc_stream_t stream);
+
+/* One feature map ("level").  Strides are in ELEMENTS, so NCHW-contiguous and channels_last (NHWC) tensors of the same
+ * logical shape are both accepted without a copy. */
+typedef struct dtc_feat_level {
+  const void* data;
+  int32_t height, width;
+  float spatial_scale;
+  int32_t _pad;
+  int64_t stride_n, stride_c, stride_h, stride_w;
+} dtc_feat_level;
+
+#define DTC_MAX_LEVELS 8
+
+/* Multi-level RoIAlign in ONE launch: replaces the per-level Python loop + torch.cat + index_select of
+ * lib/model/detector.py:263-270 and lib/model/detector.py:101-106.  rois float32 [R,roi_cols] (roi_cols 5, or 4 =
+ * batch 0 like lib/cppcuda/roi_align_cpu.cpp:143-147); roi_levels int32 [R] = index into levels[] (NULL: level 0);
+ * out [R,C,PH,PW] contiguous, written in roi order.  in_dtype/out_dtype: DTC_F32 or DTC_F16 (fp32 accumulate). */
+int dtc_roi_align_forward(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype, const float* rois,
+                          int roi_cols, const int32_t* roi_levels, int n_rois, int pooled_h, int pooled_w,
+                          int sampling_ratio, void* out, int out_dtype, dtc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DETECTORCH_HIP_H_ */

@@ -1,0 +1,136 @@
+"""A1 parity: HIP RoIAlign (through the C ABI) vs the committed golden vectors and vs the oracle.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from detectorch_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4   # north_star tolerance on RoIAlign-pooled features; the kernel is written to be bit-exact (asserted too)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from detectorch_amd import hip as h
+    h.lib()
+    return h
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("tag", ["p7s2", "p14s0", "p7s0", "p14s2", "p3x5s3"])
+def test_golden(hip, tag):
+    g = golden("roi_align")
+    ph, pw, sr, scale = g["cfg_" + tag]
+    out = hip.roi_align_forward(cu(g["features"]), float(scale), cu(g["rois5"]), int(ph), int(pw), int(sr)).cpu().numpy()
+    ref = g["out_" + tag]
+    assert np.abs(out - ref).max() <= TOL
+    assert np.array_equal(out, ref)
+
+
+def test_golden_4col_and_reference_abi(hip):
+    g = golden("roi_align")
+    f = cu(g["features"][:1])
+    out = hip.roi_align_forward(f, 1 / 16., cu(g["rois5"][:, 1:]), 7, 7, 2).cpu().numpy()
+    assert np.array_equal(out, g["out4col_p7s2"])
+    # the reference-shaped entry point (launch_roi_align_forward_cuda's argument list), caller-allocated output
+    rois = cu(g["rois5"])
+    feat = cu(g["features"])
+    R, C, H, W = rois.shape[0], feat.shape[1], feat.shape[2], feat.shape[3]
+    top = torch.zeros(R, C, 7, 7, device="cuda")
+    rc = hip.lib().launch_roi_align_forward_hip(top.numel(), feat.data_ptr(), rois.data_ptr(), 1 / 16., C, H, W, 7, 7, 2,
+                                                top.data_ptr(), hip.stream_ptr())
+    assert rc == 1
+    assert np.array_equal(top.cpu().numpy(), g["out_p7s2"])
+
+
+def test_module_surface(hip):
+    from detectorch_amd.model.roi_align import RoIAlign, RoIAlignFunction, preprocess_rois
+    g = golden("roi_align")
+    feat = cu(g["features"])
+    m = RoIAlign(7, 7, 1 / 16., 2)
+    assert np.array_equal(m(feat, cu(g["rois5"])).cpu().numpy(), g["out_p7s2"])
+    out = RoIAlignFunction.apply(feat[:1], preprocess_rois([cu(g["rois5"][:10, 1:]), cu(g["rois5"][10:, 1:])]), 7, 7,
+                                 1 / 16., 2)
+    assert np.array_equal(out.cpu().numpy(), g["out4col_p7s2"])
+    with pytest.raises(TypeError):
+        RoIAlignFunction.apply(feat, torch.from_numpy(g["rois5"]), 7, 7, 1 / 16., 2)
+    with pytest.raises(RuntimeError):
+        RoIAlignFunction.apply(feat.cpu(), torch.from_numpy(g["rois5"]), 7, 7, 1 / 16., 2)
+
+
+def test_empty(hip):
+    out = hip.roi_align_forward(torch.zeros(1, 4, 8, 8, device="cuda"), 0.25, torch.zeros(0, 5, device="cuda"), 7, 7, 2)
+    assert tuple(out.shape) == (0, 4, 7, 7)
+
+
+def _fpn_case(oracle, R, C, ph, sr, seed, batch=1):
+    rs = synth.rng(3, seed)
+    shapes = synth.fpn_level_shapes()[:4]
+    feats = [synth.make_features(rs, (batch, C, h, w)) for (h, w) in shapes]
+    rois = synth.make_rois(rs, R)
+    lv = oracle.map_rois_to_fpn_levels(rois, 2, 5) - 2
+    bidx = rs.randint(0, batch, (R, 1)).astype(np.float32)
+    rois5 = np.hstack([bidx, rois])
+    ref = np.zeros((R, C, ph, ph), np.float32)
+    for l in range(4):
+        m = lv == l
+        if m.any():
+            ref[m] = oracle.roi_align_forward(feats[l], rois5[m], ph, ph, synth.FPN_ROI_SCALES[l], sr)
+    return feats, rois5, lv.astype(np.int32), ref
+
+
+@pytest.mark.parametrize("ph,sr,R", [(7, 2, 300), (14, 2, 100)])
+def test_fpn_multilevel_vs_oracle(hip, oracle, ph, sr, R):
+    feats, rois5, lv, ref = _fpn_case(oracle, R, 32, ph, sr, ph, batch=2)
+    out = hip.roi_align_forward([cu(f) for f in feats], synth.FPN_ROI_SCALES, cu(rois5), ph, ph, sr, roi_levels=cu(lv))
+    out = out.cpu().numpy()
+    assert np.abs(out - ref).max() <= TOL
+    assert np.array_equal(out, ref)
+
+
+def test_channels_last_and_fp16(hip, oracle):
+    feats, rois5, lv, ref = _fpn_case(oracle, 120, 64, 7, 2, 77)
+    tf = [cu(f).contiguous(memory_format=torch.channels_last) for f in feats]
+    out = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, cu(rois5), 7, 7, 2, roi_levels=cu(lv)).cpu().numpy()
+    assert np.array_equal(out, ref)
+    # fp16 feature maps (BASELINE cfg5): oracle on the up-cast maps; fp32 accumulate -> exact; fp16 store -> rel 1e-3
+    h16 = [cu(f).half() for f in feats]
+    ref16 = np.zeros_like(ref)
+    for l in range(4):
+        m = lv == l
+        if m.any():
+            ref16[m] = oracle.roi_align_forward(h16[l].float().cpu().numpy(), rois5[m], 7, 7, synth.FPN_ROI_SCALES[l], 2)
+    out32 = hip.roi_align_forward(h16, synth.FPN_ROI_SCALES, cu(rois5), 7, 7, 2, roi_levels=cu(lv)).cpu().numpy()
+    assert np.array_equal(out32, ref16)
+    out16 = hip.roi_align_forward(h16, synth.FPN_ROI_SCALES, cu(rois5), 7, 7, 2, roi_levels=cu(lv),
+                                  out_dtype=torch.float16).float().cpu().numpy()
+    assert np.allclose(out16, ref16, rtol=1e-3, atol=1e-3)
+
+
+def test_c4_adaptive_sampling_full_size(hip, oracle):
+    # BASELINE cfg2 shape class: [1,C,50,84], 14x14, sampling_ratio=0 (adaptive grid up to 4x6), scale 1/16
+    rs = synth.rng(2, 5)
+    feat = synth.make_features(rs, (1, 48, 50, 84))
+    rois = np.vstack([synth.make_rois(rs, 200), [[0, 0, 1332, 799]], [[5, 5, 6, 6]]]).astype(np.float32)
+    rois5 = np.hstack([np.zeros((rois.shape[0], 1), np.float32), rois])
+    for ph in (14, 7):
+        out = hip.roi_align_forward(cu(feat), 1 / 16., cu(rois5), ph, ph, 0).cpu().numpy()
+        assert np.array_equal(out, oracle.roi_align_forward(feat, rois5, ph, ph, 1 / 16., 0))
+
+
+def test_linearity_full_size(hip):
+    # size-independent property at BASELINE cfg3's full size (R=1000, C=256, 4 levels): RoIAlign is linear in the
+    # features, roi_align(a*F) == a*roi_align(F) exactly for a power of two.
+    rs = synth.rng(3, 99)
+    shapes = synth.fpn_level_shapes()[:4]
+    feats = [torch.from_numpy(synth.make_features(rs, (1, 256, h, w))).cuda() for (h, w) in shapes]
+    rois = torch.from_numpy(np.hstack([np.zeros((1000, 1), np.float32), synth.make_rois(rs, 1000)])).cuda()
+    lv = torch.from_numpy(rs.randint(0, 4, 1000).astype(np.int32)).cuda()
+    a = hip.roi_align_forward(feats, synth.FPN_ROI_SCALES, rois, 7, 7, 2, roi_levels=lv)
+    b = hip.roi_align_forward([f * 4.0 for f in feats], synth.FPN_ROI_SCALES, rois, 7, 7, 2, roi_levels=lv)
+    assert torch.equal(a * 4.0, b)
+    assert torch.isfinite(a).all() and float(a.abs().max()) > 0
