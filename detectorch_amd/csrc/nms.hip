@@ -1,0 +1,281 @@
+// A5  Hard NMS for gfx950 -- replaces cython_nms.nms (lib/utils_cython/cython_nms.pyx:37-87; entry lib/utils/boxes.py:332).
+//
+// Segmented: one launch handles every (image, FPN level) or (image, class) segment of a batch.
+//   1. segment_sort_desc   : per segment, (score desc, index asc) order through the shared 64-bit key (block_sort.h)  [:45]
+//   2. nms_mask            : 64x64 tiles of the suppression matrix; lane <-> column box, the 64 row boxes are broadcast
+//                            through SGPRs (v_readlane with a constant lane), the 64-lane compare is collected with
+//                            __ballot into one 64-bit word per row.  IoU in the reference's float32 operation order
+//                            [:76-84]: inter / (iarea + areas[j] - inter) >= thresh, IEEE division, no contraction.
+//   3. nms_reduce          : one wavefront per segment walks the rows in score order; the in-block dependency chain is
+//                            resolved on the scalar unit over KEPT rows only (ctz loop), rows of kept boxes are OR-ed
+//                            into a register-resident `removed` bit-vector (lane l owns words l, l+64, ...).
+// Output order: positions in score order (what `keep[:post_nms_top_n]` needs, generate_proposals.py:117); dtc_nms()
+// additionally maps back to ascending original indices like np.where(suppressed == 0)[0]  [:87].
+#include "block_sort.h"
+#include "dtc_common.h"
+
+namespace dtc {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 1. segment sort.  scores [S, n_stride] (+counts) -> order [S, n_stride] int32 (original index of the k-th best),
+//    optional gathered boxes [S, n_stride, 4] / scores.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSortThreads = 1024;
+
+__global__ __launch_bounds__(kSortThreads) void segment_sort_desc_kernel(
+    const float* __restrict__ scores, int score_stride_elems, const float* __restrict__ boxes, int box_stride_elems,
+    const int32_t* __restrict__ counts, int n_stride, int32_t* __restrict__ order, float* __restrict__ sorted_boxes,
+    float* __restrict__ sorted_scores) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  const int s = blockIdx.x;
+  const int n = counts ? min(counts[s], n_stride) : n_stride;
+  const int np2 = next_pow2(n);
+  const float* sc = scores + (size_t)s * n_stride * score_stride_elems;
+  for (int i = threadIdx.x; i < np2; i += kSortThreads)
+    keys[i] = i < n ? make_desc_key(sc[(size_t)i * score_stride_elems], (uint32_t)i) : kPadKey;
+  block_bitonic_sort<kSortThreads>(keys, np2);
+  const float* bx = boxes ? boxes + (size_t)s * n_stride * box_stride_elems : nullptr;
+  for (int i = threadIdx.x; i < n; i += kSortThreads) {
+    const uint64_t k = keys[i];
+    const uint32_t src = desc_key_index(k);
+    if (order) order[(size_t)s * n_stride + i] = (int32_t)src;
+    if (sorted_scores) sorted_scores[(size_t)s * n_stride + i] = sc[(size_t)src * score_stride_elems];
+    if (sorted_boxes) {
+      const float* b = bx + (size_t)src * box_stride_elems;
+      float4 v = make_float4(b[0], b[1], b[2], b[3]);
+      reinterpret_cast<float4*>(sorted_boxes)[(size_t)s * n_stride + i] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2. suppression-matrix tiles.  boxes [S, n_stride, 4] score-sorted; mask [S, n_stride, ncb_stride] u64, only tiles with
+//    cb >= rb are written (and only those are read).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float box_area(float4 b) { return (b.z - b.x + 1.f) * (b.w - b.y + 1.f); }  // cython_nms.pyx:44
+
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ boxes,
+                                                      const int32_t* __restrict__ counts, int n_stride, int ncb_stride,
+                                                      float thresh, uint64_t* __restrict__ mask) {
+  const int cb = blockIdx.x, rb = blockIdx.y, s = blockIdx.z;
+  if (cb < rb) return;
+  const int n = counts ? min(counts[s], n_stride) : n_stride;
+  if (cb * 64 >= n) return;
+  const int lane = threadIdx.x;
+  const float4* B = boxes + (size_t)s * n_stride;
+  const int col = cb * 64 + lane, row = rb * 64 + lane;
+  const float4 cbox = col < n ? B[col] : make_float4(0.f, 0.f, -1.f, -1.f);
+  const float4 rbox = row < n ? B[row] : make_float4(0.f, 0.f, -1.f, -1.f);
+  const float carea = box_area(cbox), rarea = box_area(rbox);
+  const bool col_ok = col < n;
+  uint64_t myword = 0;
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    // row box i of this row block, broadcast through SGPRs
+    const float ix1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbox.x), i));
+    const float iy1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbox.y), i));
+    const float ix2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbox.z), i));
+    const float iy2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbox.w), i));
+    const float iarea = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rarea), i));
+    const float xx1 = fmaxf(ix1, cbox.x), yy1 = fmaxf(iy1, cbox.y);          // :76-77
+    const float xx2 = fminf(ix2, cbox.z), yy2 = fminf(iy2, cbox.w);          // :78-79
+    const float w = fmaxf(0.0f, xx2 - xx1 + 1.f), h = fmaxf(0.0f, yy2 - yy1 + 1.f);  // :80-81
+    const float inter = w * h;                                               // :82
+    const float ovr = fdiv(inter, iarea + carea - inter);                    // :83
+    const bool sup = col_ok && (col > rb * 64 + i) && (ovr >= thresh);       // :72 (_j > _i), :84
+    const uint64_t word = __ballot(sup);
+    if (lane == i) myword = word;
+  }
+  if (row < n) mask[((size_t)s * n_stride + row) * ncb_stride + cb] = myword;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3. greedy reduce, one wavefront per segment.  keep [S, keep_stride] = kept positions (score order), keep_count [S].
+//    WPL = words of `removed` per lane (supports n <= 64*64*WPL boxes).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+template <int WPL>
+__global__ __launch_bounds__(64) void nms_reduce_kernel(const uint64_t* __restrict__ mask,
+                                                        const int32_t* __restrict__ counts, int n_stride,
+                                                        int ncb_stride, int max_keep, int32_t* __restrict__ keep,
+                                                        int keep_stride, int32_t* __restrict__ keep_count) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int n = counts ? min(counts[s], n_stride) : n_stride;
+  const int ncb = (n + 63) >> 6;
+  const uint64_t* M = mask + (size_t)s * n_stride * ncb_stride;
+  int32_t* K = keep + (size_t)s * keep_stride;
+  const int cap = max_keep > 0 ? min(max_keep, keep_stride) : keep_stride;
+  uint64_t removed[WPL];
+#pragma unroll
+  for (int k = 0; k < WPL; k++) removed[k] = 0;
+  int kept = 0;
+  for (int rb = 0; rb < ncb && kept < cap; rb++) {
+    const int row = rb * 64 + lane;
+    const uint64_t diag = row < n ? M[(size_t)row * ncb_stride + rb] : 0;
+    // `removed` word of this row block lives in lane (rb & 63), slot (rb >> 6)
+    uint64_t rem = 0;
+#pragma unroll
+    for (int k = 0; k < WPL; k++)
+      if ((rb >> 6) == k) rem = readlane64(removed[k], rb & 63);
+    const int left = n - rb * 64;
+    const uint64_t valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+    uint64_t cand = valid & ~rem;
+    uint64_t keepw = 0;
+    while (cand != 0 && kept < cap) {  // scalar loop over KEPT rows only
+      const int i = __builtin_ctzll(cand);
+      keepw |= 1ull << i;
+      kept++;
+      cand &= ~(readlane64(diag, i) | (1ull << i));
+    }
+    // emit kept positions in order
+    if ((keepw >> lane) & 1ull) {
+      const int before = __builtin_popcountll(keepw & ((1ull << lane) - 1ull));
+      K[kept - __builtin_popcountll(keepw) + before] = row;
+    }
+    // removed |= OR of the kept rows (column blocks > rb only)
+    if (rb + 1 < ncb && kept < cap) {
+      uint64_t kw = keepw;
+      while (kw != 0) {
+        int r[4];
+        int m = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (kw != 0) { r[q] = __builtin_ctzll(kw); kw &= kw - 1; m = q + 1; } else { r[q] = -1; }
+        }
+        uint64_t v[4][WPL];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+          for (int k = 0; k < WPL; k++) {
+            const int c = k * 64 + lane;
+            v[q][k] = (q < m && c > rb && c < ncb) ? M[(size_t)(rb * 64 + r[q]) * ncb_stride + c] : 0ull;
+          }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+          for (int k = 0; k < WPL; k++) removed[k] |= v[q][k];
+      }
+    }
+  }
+  if (lane == 0) keep_count[s] = kept;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// finalize for the single-segment drop-in: kept positions (score order) -> ascending ORIGINAL indices, int64.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSortThreads) void nms_finalize_kernel(const int32_t* __restrict__ keep,
+                                                                    const int32_t* __restrict__ keep_count,
+                                                                    const int32_t* __restrict__ order,
+                                                                    int64_t* __restrict__ out, int32_t* __restrict__ out_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  const int n = keep_count[0];
+  const int np2 = next_pow2(n);
+  for (int i = threadIdx.x; i < np2; i += kSortThreads) keys[i] = i < n ? (uint64_t)(uint32_t)order[keep[i]] : kPadKey;
+  block_bitonic_sort<kSortThreads>(keys, np2);
+  for (int i = threadIdx.x; i < n; i += kSortThreads) out[i] = (int64_t)keys[i];
+  if (threadIdx.x == 0) *out_count = n;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace dtc
+
+// ---- C ABI ----------------------------------------------------------------------------------------------------------
+
+DTC_API size_t dtc_nms_sorted_workspace_bytes(int n_seg, int n_stride) {
+  const size_t ncb = (size_t)(n_stride + 63) / 64;
+  return dtc::align_up((size_t)n_seg * n_stride * ncb * sizeof(uint64_t), 256);
+}
+
+DTC_API int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg, int n_stride, float thresh,
+                           int max_keep, void* workspace, size_t workspace_bytes, int32_t* keep, int keep_stride,
+                           int32_t* keep_count, dtc_stream_t stream) {
+  if (n_seg < 0 || n_stride < 0 || keep_stride < 0) return DTC_EINVAL;
+  if (n_seg == 0) return DTC_OK;
+  if (!keep_count || (n_stride > 0 && (!boxes || !keep || !workspace))) return DTC_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (n_stride == 0) { return hipMemsetAsync(keep_count, 0, sizeof(int32_t) * n_seg, s) == hipSuccess ? DTC_OK : DTC_ELAUNCH; }
+  if (workspace_bytes < dtc_nms_sorted_workspace_bytes(n_seg, n_stride)) return DTC_EWORKSPACE;
+  const int ncb = (n_stride + 63) / 64;
+  if (ncb > 64 * 4) return DTC_EUNSUPPORTED;  // > 16384 boxes per segment
+  uint64_t* mask = reinterpret_cast<uint64_t*>(workspace);
+  hipLaunchKernelGGL(dtc::nms_mask_kernel, dim3(ncb, ncb, n_seg), dim3(64), 0, s,
+                     reinterpret_cast<const float4*>(boxes), counts, n_stride, ncb, thresh, mask);
+  DTC_CHECK_LAUNCH();
+  if (ncb <= 64)
+    hipLaunchKernelGGL(dtc::nms_reduce_kernel<1>, dim3(n_seg), dim3(64), 0, s, mask, counts, n_stride, ncb, max_keep, keep, keep_stride, keep_count);
+  else if (ncb <= 128)
+    hipLaunchKernelGGL(dtc::nms_reduce_kernel<2>, dim3(n_seg), dim3(64), 0, s, mask, counts, n_stride, ncb, max_keep, keep, keep_stride, keep_count);
+  else
+    hipLaunchKernelGGL(dtc::nms_reduce_kernel<4>, dim3(n_seg), dim3(64), 0, s, mask, counts, n_stride, ncb, max_keep, keep, keep_stride, keep_count);
+  DTC_CHECK_LAUNCH();
+  return DTC_OK;
+}
+
+DTC_API int dtc_segment_sort_desc(const float* scores, int score_stride_elems, const float* boxes, int box_stride_elems,
+                                  const int32_t* counts, int n_seg, int n_stride, int32_t* order, float* sorted_boxes,
+                                  float* sorted_scores, dtc_stream_t stream) {
+  if (n_seg < 0 || n_stride < 0 || n_stride > 16384 || score_stride_elems < 1) return n_stride > 16384 ? DTC_EUNSUPPORTED : DTC_EINVAL;
+  if (n_seg == 0 || n_stride == 0) return DTC_OK;
+  if (!scores || (sorted_boxes && !boxes)) return DTC_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t smem = (size_t)dtc::next_pow2(n_stride) * sizeof(uint64_t);
+  if (smem > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::segment_sort_desc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(dtc::segment_sort_desc_kernel, dim3(n_seg), dim3(dtc::kSortThreads), smem, s, scores,
+                     score_stride_elems, boxes, box_stride_elems, counts, n_stride, order, sorted_boxes, sorted_scores);
+  DTC_CHECK_LAUNCH();
+  return DTC_OK;
+}
+
+// Drop-in for cython_nms.nms(dets[N,5] float32, thresh) (lib/utils_cython/cython_nms.pyx:37): device in, device out.
+// keep_out int64 [n] receives ascending original indices, keep_count int32 [1] their number.
+DTC_API size_t dtc_nms_workspace_bytes(int n) {
+  const size_t a = dtc::align_up((size_t)n * 4 * sizeof(float), 256);    // sorted boxes
+  const size_t b = dtc::align_up((size_t)n * sizeof(int32_t), 256);      // order
+  const size_t c = dtc::align_up((size_t)n * sizeof(int32_t), 256);      // keep positions
+  const size_t d = 256;                                                  // count
+  return a + b + c + d + dtc_nms_sorted_workspace_bytes(1, n);
+}
+
+DTC_API int dtc_nms(const float* dets, int n, float thresh, void* workspace, size_t workspace_bytes, int64_t* keep_out,
+                    int32_t* keep_count, dtc_stream_t stream) {
+  if (n < 0 || !keep_count) return DTC_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (n == 0) return hipMemsetAsync(keep_count, 0, sizeof(int32_t), s) == hipSuccess ? DTC_OK : DTC_ELAUNCH;  // boxes.py:334-335
+  if (n > 16384) return DTC_EUNSUPPORTED;
+  if (!dets || !keep_out || !workspace) return DTC_EINVAL;
+  if (workspace_bytes < dtc_nms_workspace_bytes(n)) return DTC_EWORKSPACE;
+  unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
+  float* sboxes = reinterpret_cast<float*>(w); w += dtc::align_up((size_t)n * 4 * sizeof(float), 256);
+  int32_t* order = reinterpret_cast<int32_t*>(w); w += dtc::align_up((size_t)n * sizeof(int32_t), 256);
+  int32_t* keep = reinterpret_cast<int32_t*>(w); w += dtc::align_up((size_t)n * sizeof(int32_t), 256);
+  int32_t* cnt = reinterpret_cast<int32_t*>(w); w += 256;
+  int rc = dtc_segment_sort_desc(dets + 4, 5, dets, 5, nullptr, 1, n, order, sboxes, nullptr, stream);
+  if (rc != DTC_OK) return rc;
+  rc = dtc_nms_sorted(sboxes, nullptr, 1, n, thresh, 0, w, dtc_nms_sorted_workspace_bytes(1, n), keep, n, cnt, stream);
+  if (rc != DTC_OK) return rc;
+  const size_t smem = (size_t)dtc::next_pow2(n) * sizeof(uint64_t);
+  if (smem > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::nms_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(dtc::nms_finalize_kernel, dim3(1), dim3(dtc::kSortThreads), smem, s, keep, cnt, order, keep_out, keep_count);
+  DTC_CHECK_LAUNCH();
+  return DTC_OK;
+}

@@ -44,6 +44,17 @@ def lib():
     L.launch_roi_align_forward_hip.restype = i
     L.dtc_roi_align_forward.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, p, i, i, i, i, p, i, p]
     L.dtc_roi_align_forward.restype = i
+    sz = C.c_size_t
+    L.dtc_nms_workspace_bytes.argtypes = [i]
+    L.dtc_nms_workspace_bytes.restype = sz
+    L.dtc_nms.argtypes = [p, i, f, p, sz, p, p, p]
+    L.dtc_nms.restype = i
+    L.dtc_nms_sorted_workspace_bytes.argtypes = [i, i]
+    L.dtc_nms_sorted_workspace_bytes.restype = sz
+    L.dtc_nms_sorted.argtypes = [p, p, i, i, f, i, p, sz, p, i, p, p]
+    L.dtc_nms_sorted.restype = i
+    L.dtc_segment_sort_desc.argtypes = [p, i, p, i, p, i, i, p, p, p, p]
+    L.dtc_segment_sort_desc.restype = i
     _lib = L
     return L
 
@@ -121,3 +132,49 @@ def roi_align_forward(features, spatial_scales, rois, pooled_h, pooled_w, sampli
                                          stream_ptr(dev))
     check(rc, "dtc_roi_align_forward")
     return out
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def workspace(nbytes, device):
+    """uint8 scratch tensor (torch owns the memory; the kernels only see the pointer)."""
+    return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
+
+
+def nms(dets, thresh):
+    """dtc_nms: dets [N,5] float32 CUDA tensor -> int64 CUDA tensor of ascending original indices (one D2H for the count)."""
+    dev = _require_cuda(dets)
+    n = dets.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=dev)
+    dets = dets.contiguous()
+    if dets.dtype != torch.float32 or dets.dim() != 2 or dets.shape[1] != 5:
+        raise TypeError("dets must be float32 [N,5]")
+    L = lib()
+    ws = workspace(L.dtc_nms_workspace_bytes(n), dev)
+    keep = torch.empty((n,), dtype=torch.int64, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.dtc_nms(dets.data_ptr(), n, float(thresh), ws.data_ptr(), ws.numel(), keep.data_ptr(), cnt.data_ptr(),
+                       stream_ptr(dev))
+    check(rc, "dtc_nms")
+    return keep[:int(cnt.item())]
+
+
+def nms_sorted(boxes, counts, thresh, max_keep=0, keep_stride=None):
+    """dtc_nms_sorted: boxes [S,N,4] score-sorted, counts int32 [S] or None -> (keep int32 [S,keep_stride], keep_count [S])."""
+    dev = _require_cuda(boxes, counts)
+    boxes = boxes.contiguous()
+    S, N = boxes.shape[0], boxes.shape[1]
+    ks = int(keep_stride or (max_keep if max_keep > 0 else N))
+    L = lib()
+    ws = workspace(L.dtc_nms_sorted_workspace_bytes(S, N), dev)
+    keep = torch.empty((S, max(ks, 1)), dtype=torch.int32, device=dev)
+    cnt = torch.empty((max(S, 1),), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.dtc_nms_sorted(boxes.data_ptr(), _ptr(counts), S, N, float(thresh), int(max_keep), ws.data_ptr(),
+                              ws.numel(), keep.data_ptr(), ks, cnt.data_ptr(), stream_ptr(dev))
+    check(rc, "dtc_nms_sorted")
+    return keep, cnt[:S]

@@ -62,6 +62,35 @@ int dtc_roi_align_forward(const dtc_feat_level* levels, int n_levels, int channe
                           int roi_cols, const int32_t* roi_levels, int n_rois, int pooled_h, int pooled_w,
                           int sampling_ratio, void* out, int out_dtype, dtc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * A5  Hard NMS
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* Drop-in for cython_nms.nms(dets, thresh)  lib/utils_cython/cython_nms.pyx:37-87 (entry lib/utils/boxes.py:332-336).
+ * dets float32 [n,5] = (x1,y1,x2,y2,score) on the device; keep_out int64 [n] receives the ASCENDING ORIGINAL indices of
+ * the survivors (np.where(suppressed == 0)[0], :87), keep_count int32 [1] their number.  Order inside the greedy loop is
+ * (score descending, index ascending).  n <= 16384. */
+size_t dtc_nms_workspace_bytes(int n);
+int dtc_nms(const float* dets, int n, float thresh, void* workspace, size_t workspace_bytes, int64_t* keep_out,
+            int32_t* keep_count, dtc_stream_t stream);
+
+/* Segmented NMS over score-SORTED boxes: one launch for all (image, level) / (image, class) segments -- replaces the
+ * per-level loop of lib/model/detector.py:252 + generate_proposals.py:115-117 and the 80-iteration loop of
+ * lib/utils/result_utils.py:126-143.  boxes float32 [n_seg, n_stride, 4] sorted by score descending inside each
+ * segment; counts int32 [n_seg] (NULL: all n_stride valid).  keep int32 [n_seg, keep_stride] receives the kept
+ * POSITIONS in score order, at most max_keep (>0) of them (== keep[:post_nms_top_n]); keep_count int32 [n_seg]. */
+size_t dtc_nms_sorted_workspace_bytes(int n_seg, int n_stride);
+int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg, int n_stride, float thresh, int max_keep,
+                   void* workspace, size_t workspace_bytes, int32_t* keep, int keep_stride, int32_t* keep_count,
+                   dtc_stream_t stream);
+
+/* Segmented (score descending, index ascending) sort -- scores.argsort()[::-1] of cython_nms.pyx:45 with the canonical
+ * tie rule.  scores [n_seg, n_stride] read with element stride score_stride_elems (5 for a dets array); optional
+ * gather of boxes (element stride box_stride_elems between boxes) into sorted_boxes [n_seg, n_stride, 4]. */
+int dtc_segment_sort_desc(const float* scores, int score_stride_elems, const float* boxes, int box_stride_elems,
+                          const int32_t* counts, int n_seg, int n_stride, int32_t* order, float* sorted_boxes,
+                          float* sorted_scores, dtc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
