@@ -17,6 +17,13 @@ DTC_MAX_LEVELS = 8
 _ERR = {-1: "DTC_EINVAL", -2: "DTC_ELAUNCH", -3: "DTC_EWORKSPACE", -4: "DTC_EUNSUPPORTED"}
 
 
+class RpnLevel(C.Structure):
+    """struct dtc_rpn_level (include/detectorch_hip.h)"""
+    _fields_ = [("cls_prob", C.c_void_p), ("bbox_pred", C.c_void_p), ("num_anchors", C.c_int32), ("height", C.c_int32),
+                ("width", C.c_int32), ("pre_nms_top_n", C.c_int32), ("feat_stride", C.c_float), ("_pad", C.c_int32),
+                ("anchors", C.c_float * 64)]
+
+
 class FeatLevel(C.Structure):
     """struct dtc_feat_level (include/detectorch_hip.h)"""
     _fields_ = [("data", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32), ("spatial_scale", C.c_float),
@@ -55,6 +62,12 @@ def lib():
     L.dtc_nms_sorted.restype = i
     L.dtc_segment_sort_desc.argtypes = [p, i, p, i, p, i, i, p, p, p, p]
     L.dtc_segment_sort_desc.restype = i
+    L.dtc_rpn_topk_decode_workspace_bytes.argtypes = [C.POINTER(RpnLevel), i, i, i]
+    L.dtc_rpn_topk_decode_workspace_bytes.restype = sz
+    L.dtc_rpn_topk_decode.argtypes = [C.POINTER(RpnLevel), i, i, f, f, f, p, sz, p, p, p, i, p]
+    L.dtc_rpn_topk_decode.restype = i
+    L.dtc_gather_kept.argtypes = [p, p, i, i, p, p, i, p, p, p]
+    L.dtc_gather_kept.restype = i
     _lib = L
     return L
 
@@ -178,3 +191,69 @@ def nms_sorted(boxes, counts, thresh, max_keep=0, keep_stride=None):
                               ws.numel(), keep.data_ptr(), ks, cnt.data_ptr(), stream_ptr(dev))
     check(rc, "dtc_nms_sorted")
     return keep, cnt[:S]
+
+
+def make_rpn_levels(cls_probs, bbox_preds, anchors, feat_strides, pre_nms_top_n):
+    """lists (one entry per level) of [B,A,H,W] / [B,4A,H,W] float32 CUDA tensors + base anchors [A,4] -> RpnLevel array."""
+    n = len(cls_probs)
+    arr = (RpnLevel * n)()
+    keep_alive = []
+    for k in range(n):
+        c, d = cls_probs[k].contiguous(), bbox_preds[k].contiguous()
+        if c.dtype != torch.float32 or d.dtype != torch.float32:
+            raise TypeError("RPN outputs must be float32")
+        B, A, H, W = c.shape
+        if d.shape != (B, 4 * A, H, W):
+            raise ValueError("rpn_bbox_pred must be [B,4A,H,W]")
+        a = [float(v) for v in anchors[k].reshape(-1)]
+        if len(a) != 4 * A or A > 16:
+            raise ValueError("need A<=16 base anchors of 4 coordinates")
+        lv = RpnLevel(c.data_ptr(), d.data_ptr(), A, H, W, int(pre_nms_top_n[k]), float(feat_strides[k]), 0)
+        for q, v in enumerate(a):
+            lv.anchors[q] = v
+        arr[k] = lv
+        keep_alive += [c, d]
+    return arr, keep_alive
+
+
+def generate_proposals(cls_probs, bbox_preds, anchors, feat_strides, im_h, im_w, pre_nms_top_n, post_nms_top_n,
+                       nms_thresh, min_size_scaled=0.0):
+    """Batched multi-level GenerateProposals (generate_proposals.py:31-122) with zero host round trips.
+
+    Returns (boxes [B,L,P,4], scores [B,L,P], counts int32 [B,L]) with P = post_nms_top_n (rows >= count undefined),
+    plus the pre-NMS (sorted) boxes/scores/counts for callers that want them.
+    """
+    dev = _require_cuda(*cls_probs, *bbox_preds)
+    L_ = lib()
+    nl = len(cls_probs)
+    B = cls_probs[0].shape[0]
+    lv, alive = make_rpn_levels(cls_probs, bbox_preds, anchors, feat_strides, pre_nms_top_n)
+    kmax = 0
+    for k in range(nl):
+        N = cls_probs[k].shape[1] * cls_probs[k].shape[2] * cls_probs[k].shape[3]
+        K = N if (pre_nms_top_n[k] <= 0 or pre_nms_top_n[k] >= N) else int(pre_nms_top_n[k])
+        kmax = max(kmax, K)
+    S = B * nl
+    ws = workspace(L_.dtc_rpn_topk_decode_workspace_bytes(lv, nl, B, kmax), dev)
+    pre_boxes = torch.empty((S, kmax, 4), dtype=torch.float32, device=dev)
+    pre_scores = torch.empty((S, kmax), dtype=torch.float32, device=dev)
+    pre_counts = torch.empty((S,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L_.dtc_rpn_topk_decode(lv, nl, B, float(im_h), float(im_w), float(min_size_scaled), ws.data_ptr(),
+                                    ws.numel(), pre_boxes.data_ptr(), pre_scores.data_ptr(), pre_counts.data_ptr(),
+                                    kmax, stream_ptr(dev))
+    check(rc, "dtc_rpn_topk_decode")
+    if nms_thresh <= 0:                                   # generate_proposals.py:114
+        return (pre_boxes.view(B, nl, kmax, 4), pre_scores.view(B, nl, kmax), pre_counts.view(B, nl),
+                pre_boxes, pre_scores, pre_counts)
+    P = int(post_nms_top_n) if post_nms_top_n > 0 else kmax
+    P = min(P, kmax)
+    keep, kcnt = nms_sorted(pre_boxes, pre_counts, nms_thresh, max_keep=P, keep_stride=P)
+    out_boxes = torch.empty((S, P, 4), dtype=torch.float32, device=dev)
+    out_scores = torch.empty((S, P), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L_.dtc_gather_kept(pre_boxes.data_ptr(), pre_scores.data_ptr(), S, kmax, keep.data_ptr(), kcnt.data_ptr(),
+                                P, out_boxes.data_ptr(), out_scores.data_ptr(), stream_ptr(dev))
+    check(rc, "dtc_gather_kept")
+    del alive
+    return (out_boxes.view(B, nl, P, 4), out_scores.view(B, nl, P), kcnt.view(B, nl), pre_boxes, pre_scores, pre_counts)

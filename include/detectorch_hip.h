@@ -91,6 +91,43 @@ int dtc_segment_sort_desc(const float* scores, int score_stride_elems, const flo
                           const int32_t* counts, int n_seg, int n_stride, int32_t* order, float* sorted_boxes,
                           float* sorted_scores, dtc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * A2 + A3 + A4  RPN proposals: anchors, pre-NMS top-k, decode, clip, filter -- all images, all FPN levels
+ * --------------------------------------------------------------------------------------------------------------- */
+
+#define DTC_RPN_MAX_LEVELS 8
+#define DTC_RPN_MAX_ANCHORS 16
+
+/* One RPN head output (one FPN level, or the single C4 map) for a whole batch, in the conv's native layout:
+ * cls_prob float32 [B, A, H, W] (post-sigmoid, lib/model/detector.py:125), bbox_pred float32 [B, 4A, H, W].
+ * anchors = the A base anchors of generate_anchors(stride=feat_stride, ...) (lib/utils/generate_anchors.py:54-65),
+ * row-major [A,4]; feat_stride = 1/spatial_scale (generate_proposals.py:130). pre_nms_top_n <= 0 means "all". */
+typedef struct dtc_rpn_level {
+  const float* cls_prob;
+  const float* bbox_pred;
+  int32_t num_anchors, height, width;
+  int32_t pre_nms_top_n;
+  float feat_stride;
+  int32_t _pad;
+  float anchors[DTC_RPN_MAX_ANCHORS * 4];
+} dtc_rpn_level;
+
+/* Steps 1-5 of GenerateProposals.forward (lib/model/generate_proposals.py:31-109) for every (image, level) segment
+ * s = b * n_levels + l.  Outputs, per segment, in DESCENDING score order (ties: ascending (h,w,a) index):
+ *   out_boxes float32 [B*L, k_stride, 4], out_scores float32 [B*L, k_stride], out_counts int32 [B*L]
+ * i.e. exactly the `dets` the reference hands to NMS at :115.  k_stride >= max_l min(pre_nms_top_n_l, N_l) (0: that max).
+ * (im_h, im_w) is the network input size (:100), min_size_scaled = rpn_min_size * scaling_factor (:154). */
+size_t dtc_rpn_topk_decode_workspace_bytes(const dtc_rpn_level* levels, int n_levels, int batch, int k_stride);
+int dtc_rpn_topk_decode(const dtc_rpn_level* levels, int n_levels, int batch, float im_h, float im_w,
+                        float min_size_scaled, void* workspace, size_t workspace_bytes, float* out_boxes,
+                        float* out_scores, int32_t* out_counts, int k_stride, dtc_stream_t stream);
+
+/* proposals[keep] / scores[keep] of generate_proposals.py:119-120 for every segment: out_boxes [n_seg, keep_stride, 4],
+ * out_scores [n_seg, keep_stride] (rows >= keep_count[s] untouched). */
+int dtc_gather_kept(const float* sorted_boxes, const float* sorted_scores, int n_seg, int k_stride, const int32_t* keep,
+                    const int32_t* keep_count, int keep_stride, float* out_boxes, float* out_scores,
+                    dtc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

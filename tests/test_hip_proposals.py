@@ -1,0 +1,124 @@
+"""A2-A4 (+A5) parity: HIP GenerateProposals vs the golden vectors produced by the reference's own Python, and vs the
+oracle at full BASELINE sizes.  Survivor identity/order (scores are unique keys) must match exactly; box coordinates
+within 1e-4 / 1 ulp of the reference (its exp is torch-CPU), and BIT-EXACT vs the oracle.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, ulp_close
+from detectorch_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from detectorch_amd import hip as h
+    h.lib()
+    return h
+
+
+@pytest.mark.parametrize("tag", ["c4", "p3", "p6"])
+def test_golden_module_surface(hip, tag):
+    from detectorch_amd.model.generate_proposals import GenerateProposals
+    g = golden("generate_proposals")
+    cfg = g[tag + "_cfg"]
+    ss, pre, post, im_h, im_w = cfg[3], int(cfg[4]), int(cfg[5]), cfg[6], cfg[7]
+    gp = GenerateProposals(spatial_scale=ss, anchor_sizes=tuple(cfg[9:]), rpn_pre_nms_top_n=pre, rpn_post_nms_top_n=post)
+    props, scores = gp(torch.from_numpy(g[tag + "_cls"]).cuda(), torch.from_numpy(g[tag + "_bbox"]).cuda(), im_h, im_w, 1.6)
+    assert props.is_cuda and scores.is_cuda and scores.dim() == 2 and scores.shape[1] == 1
+    assert np.array_equal(scores.cpu().numpy(), g[tag + "_scores"])
+    assert ulp_close(props.cpu().numpy(), g[tag + "_props"])
+
+
+def _oracle_levels(oracle, cls, bbox, sizes, strides, im_h, im_w, pre, post, thr):
+    out = []
+    for l in range(len(cls)):
+        anchors = oracle.generate_anchors(strides[l], (sizes[l],) if np.isscalar(sizes[l]) else sizes[l], (0.5, 1, 2))
+        per_img = []
+        for b in range(cls[l].shape[0]):
+            per_img.append(oracle.generate_proposals(cls[l][b], bbox[l][b], anchors, strides[l], im_h, im_w, pre[l], post,
+                                                     thr, return_pre_nms=True))
+        out.append(per_img)
+    return out
+
+
+def test_fpn_batched_full_size_vs_oracle(hip, oracle):
+    # BASELINE cfg3: 5 FPN levels of a 800x1344 input, pre 1000 / post 1000 per level, 2 images in one call
+    from detectorch_amd.utils.generate_anchors import generate_anchors
+    shapes = synth.fpn_level_shapes()
+    B = 2
+    cls, bbox = [], []
+    for l, (h, w) in enumerate(shapes):
+        cs, bs = [], []
+        for b in range(B):
+            c, d = synth.make_rpn_outputs(synth.rng(3, 10 * l + b), 3, h, w)
+            cs.append(c); bs.append(d)
+        cls.append(np.concatenate(cs)); bbox.append(np.concatenate(bs))
+    strides = [float(s) for s in synth.FPN_STRIDES]
+    sizes = [32.0 * 2 ** l for l in range(5)]
+    anchors = [generate_anchors(stride=strides[l], sizes=(sizes[l],), aspect_ratios=(0.5, 1, 2)) for l in range(5)]
+    boxes, scores, counts, pb, ps, pc = hip.generate_proposals(
+        [torch.from_numpy(c).cuda() for c in cls], [torch.from_numpy(d).cuda() for d in bbox], anchors, strides,
+        synth.FPN_PAD_H, synth.FPN_PAD_W, [1000] * 5, 1000, 0.7)
+    ref = _oracle_levels(oracle, cls, bbox, sizes, strides, synth.FPN_PAD_H, synth.FPN_PAD_W, [1000] * 5, 1000, 0.7)
+    boxes, scores, counts = boxes.cpu().numpy(), scores.cpu().numpy(), counts.cpu().numpy()
+    pb, ps, pc = pb.cpu().numpy(), ps.cpu().numpy(), pc.cpu().numpy()
+    for l in range(5):
+        for b in range(B):
+            rb, rs, rpb, rps = ref[l][b]
+            s = b * 5 + l
+            assert pc[s] == rps.shape[0]
+            assert np.array_equal(ps[s, :pc[s]], rps)            # pre-NMS: same top-k, same order
+            assert np.array_equal(pb[s, :pc[s]], rpb)            # decode/clip bit-exact vs the oracle
+            assert counts[b, l] == rs.shape[0]
+            assert np.array_equal(scores[b, l, :counts[b, l]], rs)
+            assert np.array_equal(boxes[b, l, :counts[b, l]], rb)
+
+
+def test_c4_full_size_vs_oracle(hip, oracle):
+    # BASELINE cfg2: A=15 on 50x84 (63 000 anchors), pre-NMS 6000, post 1000, thresh 0.7
+    from detectorch_amd.model.generate_proposals import GenerateProposals
+    c, d = synth.make_rpn_outputs(synth.rng(2, 0), 15, 50, 84)
+    gp = GenerateProposals()
+    props, scores = gp(torch.from_numpy(c).cuda(), torch.from_numpy(d).cuda(), 800, 1333, 1.6)
+    rb, rs = oracle.generate_proposals(c[0], d[0], oracle.generate_anchors(16.0), 16.0, 800, 1333, 6000, 1000, 0.7)
+    assert np.array_equal(scores.cpu().numpy().reshape(-1), rs)
+    assert np.array_equal(props.cpu().numpy(), rb)
+
+
+def test_ties_and_constant_maps(hip, oracle):
+    # (1) heavy exact ties (quantised scores) (2) a constant score map: every element ties at the threshold -> the
+    # canonical rule (lowest (h,w,a) index first) must hold, including through the massive-tie fallback path.
+    from detectorch_amd.utils.generate_anchors import generate_anchors
+    rs = synth.rng(3, 777)
+    A, H, W = 3, 50, 84
+    c, d = synth.make_rpn_outputs(rs, A, H, W, tie_free=False)
+    quant = (np.round(c * 16) / 16).astype(np.float32)
+    const = np.full_like(c, 0.25)
+    anchors = generate_anchors(stride=16.0, sizes=(128.0,), aspect_ratios=(0.5, 1, 2))
+    for sc in (quant, const):
+        _, _, _, pb, ps, pc = hip.generate_proposals([torch.from_numpy(sc).cuda()], [torch.from_numpy(d).cuda()], [anchors],
+                                                     [16.0], 800, 1344, [1000], 1000, 0.7)
+        _, _, rpb, rps = oracle.generate_proposals(sc[0], d[0], anchors, 16.0, 800, 1344, 1000, 1000, 0.7,
+                                                   return_pre_nms=True)
+        n = int(pc.cpu().numpy()[0])
+        assert n == rps.shape[0]
+        assert np.array_equal(ps.cpu().numpy()[0, :n], rps)
+        assert np.array_equal(pb.cpu().numpy()[0, :n], rpb)
+
+
+def test_sortedness_property(hip):
+    # size-independent property: pre-NMS scores are non-increasing and every box is inside the image
+    from detectorch_amd.utils.generate_anchors import generate_anchors
+    c, d = synth.make_rpn_outputs(synth.rng(3, 5), 3, 200, 336)
+    anchors = generate_anchors(stride=4.0, sizes=(32.0,), aspect_ratios=(0.5, 1, 2))
+    _, _, _, pb, ps, pc = hip.generate_proposals([torch.from_numpy(c).cuda()], [torch.from_numpy(d).cuda()], [anchors], [4.0],
+                                                 800, 1344, [1000], 1000, 0.7)
+    n = int(pc[0].item())
+    s = ps[0, :n]
+    assert n == 1000 and bool((s[:-1] >= s[1:]).all())
+    b = pb[0, :n]
+    assert float(b.min()) >= 0 and float(b[:, 2].max()) <= 1343 and float(b[:, 3].max()) <= 799
+    top = torch.topk(torch.from_numpy(c).reshape(-1), 1000).values
+    assert torch.equal(s.cpu(), top)
