@@ -1,0 +1,320 @@
+// A8  Detection post-processing for gfx950 -- replaces postprocess_output (lib/utils/result_utils.py:76-94) and
+// box_results_with_nms_and_limit (:96-168, hard-NMS branch), which run on the host: 3 D2H copies, numpy decode of all
+// R x 81 boxes, an 80-iteration Python loop calling Cython NMS, np.sort for the per-image limit.
+//
+//   det_candidates   grid (class, image): score > thresh (:127) -> ordered compaction (dets_j order), class-specific box
+//                    decode with weights (10,10,5,5) (lib/utils/boxes.py:168-208) ONLY for the candidates, clip to the
+//                    original image (:150-165), (score desc, index asc) sort in LDS -> NMS input
+//   dtc_nms_sorted   all B x 80 segments in one launch (nms.hip)
+//   det_finalize     grid (image): max_detections_per_img limit (:154-163) = radix select of the 100-th largest score,
+//                    `>=` filter (ties kept, like the reference), class-major / roi-ascending output (:165).
+#include "block_sort.h"
+#include "dtc_common.h"
+#include "radix_select.h"
+
+namespace dtc {
+
+constexpr int kDetThreads = 256;
+
+struct DetParams {
+  const float* rois5;        // [B, R, 5]
+  const int32_t* n_rois;     // [B] or NULL (all R valid)
+  const float* cls_score;    // [B, R, n_cls]
+  const float* bbox_pred;    // [B, R, 4*n_cls]
+  const float* scale;        // [B] scaling factor per image
+  const float* im_size;      // [B, 2] original (h, w)
+  int R, n_cls;
+  float wx, wy, ww, wh, score_thresh;
+  // per (image, class) segment s = b*(n_cls-1) + (j-1), stride R
+  float* sorted_boxes;       // [S, R, 4]   score order (NMS input)
+  int32_t* q_of_k;           // [S, R]      sorted rank -> candidate index in dets_j (roi-ascending) order
+  float* q_boxes;            // [S, R, 4]   candidate order
+  float* q_scores;           // [S, R]
+  int32_t* q_roi;            // [S, R]
+  int32_t* cand_count;       // [S]
+};
+
+// lib/utils/boxes.py:168-208 for one (roi, class)
+__device__ __forceinline__ void decode_det(const float roi[4], float sf, const float* d, float wx, float wy, float ww,
+                                           float wh, float im_h, float im_w, float out[4]) {
+  const float x1 = fdiv(roi[0], sf), y1 = fdiv(roi[1], sf), x2 = fdiv(roi[2], sf), y2 = fdiv(roi[3], sf);  // result_utils.py:77
+  const float widths = x2 - x1 + 1.0f, heights = y2 - y1 + 1.0f;           // boxes.py:178-179
+  const float ctr_x = x1 + 0.5f * widths, ctr_y = y1 + 0.5f * heights;     // :180-181
+  const float dx = fdiv(d[0], wx), dy = fdiv(d[1], wy);                    // :184-185
+  float dw = fdiv(d[2], ww), dh = fdiv(d[3], wh);                          // :186-187
+  const float clipv = 4.135166556742356f;                                  // :73
+  dw = fminf(dw, clipv); dh = fminf(dh, clipv);                            // :190-191
+  const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;       // :193-194
+  const float pw = fexp_cr(dw) * widths, ph = fexp_cr(dh) * heights;       // :195-196
+  float b0 = pcx - 0.5f * pw, b1 = pcy - 0.5f * ph;                        // :200-202
+  float b2 = pcx + 0.5f * pw - 1.f, b3 = pcy + 0.5f * ph - 1.f;            // :204-206
+  out[0] = fmaxf(fminf(b0, im_w - 1.f), 0.f); out[1] = fmaxf(fminf(b1, im_h - 1.f), 0.f);  // :158-164
+  out[2] = fmaxf(fminf(b2, im_w - 1.f), 0.f); out[3] = fmaxf(fminf(b3, im_h - 1.f), 0.f);
+}
+
+__global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  __shared__ int wave_tot[kDetThreads / 64];
+  __shared__ int running;
+  const int j = blockIdx.x + 1, b = blockIdx.y;
+  const int seg = b * (p.n_cls - 1) + (j - 1);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nr = p.n_rois ? min(p.n_rois[b], p.R) : p.R;
+  const float* sc = p.cls_score + (size_t)b * p.R * p.n_cls + j;
+  int32_t* qroi = p.q_roi + (size_t)seg * p.R;
+  float* qs = p.q_scores + (size_t)seg * p.R;
+  if (tid == 0) running = 0;
+  __syncthreads();
+  // ordered compaction of {r : scores[r, j] > thresh}  (np.where, result_utils.py:127)
+  for (int r0 = 0; r0 < nr; r0 += kDetThreads) {
+    const int r = r0 + tid;
+    float s = 0.f;
+    bool ok = false;
+    if (r < nr) { s = sc[(size_t)r * p.n_cls]; ok = s > p.score_thresh; }
+    const uint64_t m = __ballot(ok);
+    if (lane == 0) wave_tot[wv] = __builtin_popcountll(m);
+    __syncthreads();
+    int base = running;
+    for (int q = 0; q < wv; q++) base += wave_tot[q];
+    if (ok) {
+      const int q = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      qroi[q] = r; qs[q] = s;
+      keys[q] = make_desc_key(s, (uint32_t)q);
+    }
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int q = 0; q < kDetThreads / 64; q++) t += wave_tot[q]; running += t; }
+    __syncthreads();
+  }
+  const int n = running;
+  if (tid == 0) p.cand_count[seg] = n;
+  if (n == 0) return;
+  const int np2 = next_pow2(n);
+  for (int i = n + tid; i < np2; i += kDetThreads) keys[i] = kPadKey;
+  block_bitonic_sort<kDetThreads>(keys, np2);
+  // decode candidate q (once), then emit both the candidate-order and the score-order copies
+  const float sf = p.scale[b];
+  const float im_h = p.im_size[b * 2 + 0], im_w = p.im_size[b * 2 + 1];
+  float4* qb = reinterpret_cast<float4*>(p.q_boxes) + (size_t)seg * p.R;
+  for (int q = tid; q < n; q += kDetThreads) {
+    const int r = qroi[q];
+    const float* roi = p.rois5 + ((size_t)b * p.R + r) * 5 + 1;
+    const float* d = p.bbox_pred + ((size_t)b * p.R + r) * 4 * p.n_cls + 4 * j;
+    const float rr[4] = {roi[0], roi[1], roi[2], roi[3]};
+    float o[4];
+    decode_det(rr, sf, d, p.wx, p.wy, p.ww, p.wh, im_h, im_w, o);
+    qb[q] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  __syncthreads();
+  float4* sb = reinterpret_cast<float4*>(p.sorted_boxes) + (size_t)seg * p.R;
+  int32_t* qk = p.q_of_k + (size_t)seg * p.R;
+  for (int k = tid; k < n; k += kDetThreads) {
+    const int q = (int)desc_key_index(keys[k]);
+    qk[k] = q;
+    sb[k] = qb[q];
+  }
+}
+
+constexpr int kFinThreads = 1024;
+constexpr int kFinMaxCls = 256;
+
+struct FinParams {
+  const int32_t* keep;        // [S, R] kept ranks (score order) from dtc_nms_sorted
+  const int32_t* keep_count;  // [S]
+  const int32_t* q_of_k;      // [S, R]
+  const float* q_boxes;       // [S, R, 4]
+  const float* q_scores;      // [S, R]
+  const int32_t* q_roi;       // [S, R]
+  const float* scale;         // [B]
+  int R, n_cls, max_det, max_out;
+  float* dets;                // [B, max_out, 6]
+  int32_t* det_roi;           // [B, max_out]
+  float* det_rois_scaled;     // [B, max_out, 4]  boxes * scaling_factor (eval_mask_FPN.ipynb:249), may be NULL
+  int32_t* det_count;         // [B]
+};
+
+__global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) {
+  __shared__ uint32_t h[2048];
+  __shared__ uint32_t sh[2];
+  __shared__ int koff[kFinMaxCls + 1];
+  __shared__ int ccnt[kFinMaxCls];
+  __shared__ int coff[kFinMaxCls + 1];
+  __shared__ uint64_t bitmap[kFinThreads / 64][64];  // per wave: up to 4096 candidates per class
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nseg = p.n_cls - 1;
+  const int seg0 = b * nseg;
+  if (tid == 0) {
+    int acc = 0;
+    for (int c = 0; c < nseg; c++) { koff[c] = acc; acc += p.keep_count[seg0 + c]; }
+    koff[nseg] = acc;
+  }
+  __syncthreads();
+  const int total = koff[nseg];
+  // ---- per-image limit (result_utils.py:154-163): threshold = max_det-th largest kept score ----
+  uint32_t T = 0;  // ordered-key threshold; 0 == keep everything
+  if (p.max_det > 0 && total > p.max_det) {
+    uint32_t prefix = 0, krem = (uint32_t)p.max_det;
+    for (int pass = 0; pass < 3; pass++) {
+      for (int i = tid; i < 2048; i += kFinThreads) h[i] = 0;
+      __syncthreads();
+      for (int f = tid; f < total; f += kFinThreads) {
+        int lo = 0, hi = nseg;  // class c with koff[c] <= f < koff[c+1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (koff[mid] <= f) lo = mid; else hi = mid; }
+        const int seg = seg0 + lo, e = f - koff[lo];
+        const int q = p.q_of_k[(size_t)seg * p.R + p.keep[(size_t)seg * p.R + e]];
+        const uint32_t o = float_to_ordered(p.q_scores[(size_t)seg * p.R + q]);
+        if (pass == 0) atomicAdd(&h[o >> 21], 1u);
+        else if (pass == 1) { if ((o >> 21) == prefix) atomicAdd(&h[(o >> 10) & 2047u], 1u); }
+        else { if ((o >> 10) == prefix) atomicAdd(&h[o & 1023u], 1u); }
+      }
+      __syncthreads();
+      select_digit(h, pass == 2 ? 1024 : 2048, krem, sh);
+      prefix = (prefix << (pass == 2 ? 10 : 11)) | sh[0];
+      krem = sh[1];
+      __syncthreads();
+    }
+    T = prefix;
+  }
+  // ---- pass A: survivors per class ----
+  for (int c = wv; c < nseg; c += kFinThreads / 64) {
+    const int seg = seg0 + c, nk = p.keep_count[seg];
+    int cnt = 0;
+    for (int e0 = 0; e0 < nk; e0 += 64) {
+      const int e = e0 + lane;
+      bool ok = false;
+      if (e < nk) {
+        const int q = p.q_of_k[(size_t)seg * p.R + p.keep[(size_t)seg * p.R + e]];
+        ok = float_to_ordered(p.q_scores[(size_t)seg * p.R + q]) >= T;       // :161 `>=`
+      }
+      cnt += __builtin_popcountll(__ballot(ok));
+    }
+    if (lane == 0) ccnt[c] = cnt;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int c = 0; c < nseg; c++) { coff[c] = acc; acc += ccnt[c]; }
+    coff[nseg] = acc;
+    p.det_count[b] = acc;
+  }
+  __syncthreads();
+  // ---- pass B: class-major, candidate(roi)-ascending output (:143 dets_j[keep], :165 vstack) ----
+  const float sf = p.scale[b];
+  for (int c = wv; c < nseg; c += kFinThreads / 64) {
+    const int seg = seg0 + c, nk = p.keep_count[seg];
+    if (ccnt[c] == 0) continue;
+    uint64_t* bm = bitmap[wv];
+    bm[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int e0 = 0; e0 < nk; e0 += 64) {
+      const int e = e0 + lane;
+      if (e < nk) {
+        const int q = p.q_of_k[(size_t)seg * p.R + p.keep[(size_t)seg * p.R + e]];
+        if (float_to_ordered(p.q_scores[(size_t)seg * p.R + q]) >= T && q < 4096)
+          atomicOr(reinterpret_cast<unsigned long long*>(&bm[q >> 6]), 1ull << (q & 63));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint64_t w = bm[lane];
+    // exclusive prefix of popcounts across lanes
+    int pc = __builtin_popcountll(w), incl = pc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    int slot = coff[c] + incl - pc;
+    while (w) {
+      const int bit = __builtin_ctzll(w);
+      w &= w - 1;
+      const int q = lane * 64 + bit;
+      if (slot < p.max_out) {
+        const float4 bx = reinterpret_cast<const float4*>(p.q_boxes)[(size_t)seg * p.R + q];
+        float* o = p.dets + ((size_t)b * p.max_out + slot) * 6;
+        o[0] = bx.x; o[1] = bx.y; o[2] = bx.z; o[3] = bx.w;
+        o[4] = p.q_scores[(size_t)seg * p.R + q];
+        o[5] = (float)(c + 1);
+        p.det_roi[(size_t)b * p.max_out + slot] = p.q_roi[(size_t)seg * p.R + q];
+        if (p.det_rois_scaled)
+          reinterpret_cast<float4*>(p.det_rois_scaled)[(size_t)b * p.max_out + slot] =
+              make_float4(bx.x * sf, bx.y * sf, bx.z * sf, bx.w * sf);
+      }
+      slot++;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace dtc
+
+extern "C" size_t dtc_nms_sorted_workspace_bytes(int n_seg, int n_stride);
+extern "C" int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg, int n_stride, float thresh,
+                              int max_keep, void* workspace, size_t workspace_bytes, int32_t* keep, int keep_stride,
+                              int32_t* keep_count, dtc_stream_t stream);
+
+namespace dtc {
+struct DetPlan { size_t sorted_boxes, q_of_k, q_boxes, q_scores, q_roi, cand_count, keep, keep_count, nms, total; };
+static DetPlan det_plan(int batch, int R, int n_cls) {
+  DetPlan d;
+  const size_t S = (size_t)batch * (n_cls - 1);
+  size_t o = 0;
+  d.sorted_boxes = o; o += al256(S * R * 4 * sizeof(float));
+  d.q_of_k = o; o += al256(S * R * sizeof(int32_t));
+  d.q_boxes = o; o += al256(S * R * 4 * sizeof(float));
+  d.q_scores = o; o += al256(S * R * sizeof(float));
+  d.q_roi = o; o += al256(S * R * sizeof(int32_t));
+  d.cand_count = o; o += al256(S * sizeof(int32_t));
+  d.keep = o; o += al256(S * R * sizeof(int32_t));
+  d.keep_count = o; o += al256(S * sizeof(int32_t));
+  d.nms = o; o += dtc_nms_sorted_workspace_bytes((int)S, R);
+  d.total = o;
+  return d;
+}
+}  // namespace dtc
+
+DTC_API size_t dtc_postprocess_detections_workspace_bytes(int batch, int max_rois, int n_cls) {
+  if (batch < 1 || max_rois < 1 || n_cls < 2) return 0;
+  return dtc::det_plan(batch, max_rois, n_cls).total;
+}
+
+DTC_API int dtc_postprocess_detections(const float* rois5, const int32_t* n_rois, const float* cls_score,
+                                       const float* bbox_pred, const float* scaling_factor, const float* im_size,
+                                       int batch, int max_rois, int n_cls, float wx, float wy, float ww, float wh,
+                                       float score_thresh, float nms_thresh, int max_det, void* workspace,
+                                       size_t workspace_bytes, float* dets, int32_t* det_roi, float* det_rois_scaled,
+                                       int32_t* det_count, int max_out, dtc_stream_t stream) {
+  if (batch < 0 || max_rois < 1 || n_cls < 2 || n_cls - 1 > dtc::kFinMaxCls || max_out < 1) return DTC_EINVAL;
+  if (batch == 0) return DTC_OK;
+  if (max_rois > 4096) return DTC_EUNSUPPORTED;
+  if (!rois5 || !cls_score || !bbox_pred || !scaling_factor || !im_size || !workspace || !dets || !det_roi || !det_count)
+    return DTC_EINVAL;
+  const dtc::DetPlan pl = dtc::det_plan(batch, max_rois, n_cls);
+  if (workspace_bytes < pl.total) return DTC_EWORKSPACE;
+  unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int S = batch * (n_cls - 1);
+  dtc::DetParams p;
+  p.rois5 = rois5; p.n_rois = n_rois; p.cls_score = cls_score; p.bbox_pred = bbox_pred; p.scale = scaling_factor;
+  p.im_size = im_size; p.R = max_rois; p.n_cls = n_cls; p.wx = wx; p.wy = wy; p.ww = ww; p.wh = wh;
+  p.score_thresh = score_thresh;
+  p.sorted_boxes = reinterpret_cast<float*>(w + pl.sorted_boxes); p.q_of_k = reinterpret_cast<int32_t*>(w + pl.q_of_k);
+  p.q_boxes = reinterpret_cast<float*>(w + pl.q_boxes); p.q_scores = reinterpret_cast<float*>(w + pl.q_scores);
+  p.q_roi = reinterpret_cast<int32_t*>(w + pl.q_roi); p.cand_count = reinterpret_cast<int32_t*>(w + pl.cand_count);
+  const size_t smem = (size_t)dtc::next_pow2(max_rois) * sizeof(uint64_t);
+  hipLaunchKernelGGL(dtc::det_candidates_kernel, dim3(n_cls - 1, batch), dim3(dtc::kDetThreads), smem, s, p);
+  DTC_CHECK_LAUNCH();
+  int32_t* keep = reinterpret_cast<int32_t*>(w + pl.keep);
+  int32_t* keep_count = reinterpret_cast<int32_t*>(w + pl.keep_count);
+  int rc = dtc_nms_sorted(p.sorted_boxes, p.cand_count, S, max_rois, nms_thresh, 0, w + pl.nms,
+                          dtc_nms_sorted_workspace_bytes(S, max_rois), keep, max_rois, keep_count, stream);
+  if (rc != DTC_OK) return rc;
+  dtc::FinParams f;
+  f.keep = keep; f.keep_count = keep_count; f.q_of_k = p.q_of_k; f.q_boxes = p.q_boxes; f.q_scores = p.q_scores;
+  f.q_roi = p.q_roi; f.scale = scaling_factor; f.R = max_rois; f.n_cls = n_cls; f.max_det = max_det; f.max_out = max_out;
+  f.dets = dets; f.det_roi = det_roi; f.det_rois_scaled = det_rois_scaled; f.det_count = det_count;
+  hipLaunchKernelGGL(dtc::det_finalize_kernel, dim3(batch), dim3(dtc::kFinThreads), 0, s, f);
+  DTC_CHECK_LAUNCH();
+  return DTC_OK;
+}

@@ -1,0 +1,167 @@
+// A7  FPN collect + distribute for gfx950 -- replaces
+//   collect      lib/model/collect_and_distribute_fpn_rpn_proposals.py:84-105  (cat + torch.sort + top post_nms_topN)
+//   distribute   :108-128 (D2H + numpy level mapping + np.where per level + argsort)
+//   map_rois_to_fpn_levels   lib/utils/multilevel_rois.py:41-53 ; add_multilevel_rois_for_test :19-39 (mask branch)
+// One workgroup per image, everything stays on the device.  Besides the reference's outputs (per-level roi lists +
+// idx_restore) it emits what the multi-level RoIAlign kernel consumes directly: rois5 in collected order + a level id per
+// RoI, so the pooled features come out already "restored" (no cat / index_select, lib/model/detector.py:266-270).
+#include "block_sort.h"
+#include "dtc_common.h"
+
+namespace dtc {
+
+constexpr int kFpnThreads = 1024;
+constexpr int kFpnMaxLevels = 8;
+
+// lib/utils/multilevel_rois.py:47-52 in float32 numpy arithmetic (boxes_area: lib/utils/boxes.py:77-79)
+__device__ __forceinline__ int fpn_level(float x1, float y1, float x2, float y2, int k_min, int k_max) {
+  const float area = (x2 - x1 + 1.f) * (y2 - y1 + 1.f);
+  const float s = fsqrt(area);
+  float t = floorf(4.f + flog2_cr(fdiv(s, 224.f) + 1e-6f));
+  t = fminf(fmaxf(t, (float)k_min), (float)k_max);
+  return (int)t;
+}
+
+struct FpnParams {
+  const float* in_boxes;     // [B, L_in, P, 4]
+  const float* in_scores;    // [B, L_in, P]     (NULL: no sort, take the first counts[b*L_in] rows of level 0 as they are)
+  const int32_t* in_counts;  // [B, L_in]
+  int L_in, P, top_n, k_min, k_max;
+  float* rois5;              // [B, top_n, 5]   (b, x1, y1, x2, y2) in collected (score) order
+  float* roi_scores;         // [B, top_n]      (may be NULL)
+  int32_t* roi_levels;       // [B, top_n]      level - k_min, or -1 for rows >= n_out[b]
+  int32_t* n_out;            // [B]
+  float* rois_by_level;      // [B, top_n, 4]   rows grouped by level (the reference's distr_rois, concatenated)
+  int32_t* level_counts;     // [B, k_max-k_min+1]
+  int32_t* idx_restore;      // [B, top_n]      rois_by_level[idx_restore[r]] == roi r
+};
+
+__global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(FpnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  __shared__ int lvl_off[kFpnMaxLevels + 1];
+  __shared__ int in_off[kFpnMaxLevels + 1];
+  __shared__ int wave_cnt[kFpnMaxLevels][kFpnThreads / 64];
+  __shared__ int lvl_run[kFpnMaxLevels];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nl_out = p.k_max - p.k_min + 1;
+  if (tid == 0) {
+    int acc = 0;
+    for (int l = 0; l < p.L_in; l++) { in_off[l] = acc; acc += min(p.in_counts[b * p.L_in + l], p.P); }
+    in_off[p.L_in] = acc;
+  }
+  if (tid < kFpnMaxLevels) lvl_run[tid] = 0;
+  __syncthreads();
+  const int n = in_off[p.L_in];
+  const int m = min(n, p.top_n);                                   // :104
+  const float* boxes = p.in_boxes + (size_t)b * p.L_in * p.P * 4;
+  int np2 = 2;
+  if (p.in_scores) {
+    const float* scores = p.in_scores + (size_t)b * p.L_in * p.P;
+    np2 = next_pow2(n);
+    for (int i = tid; i < np2; i += kFpnThreads) {
+      uint64_t k = kPadKey;
+      if (i < n) {
+        int l = 0;
+        for (int q = 1; q < p.L_in; q++) if (i >= in_off[q]) l = q;
+        const int j = i - in_off[l];
+        // key index = position in the concatenation (:95-97): ties resolve to the earlier level / earlier row.
+        // low 32 bits carry the concat index; the (level,row) source is recovered from it.
+        k = make_desc_key(scores[(size_t)l * p.P + j], (uint32_t)i);
+      }
+      keys[i] = k;
+    }
+    block_bitonic_sort<kFpnThreads>(keys, np2);                     // :102
+  }
+  // ranks [0, m): roi, level, distribution
+  for (int r0 = 0; r0 < p.top_n; r0 += kFpnThreads) {
+    const int r = r0 + tid;
+    int lvl = -1;
+    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sc = 0.f;
+    if (r < m) {
+      int src = r;
+      if (p.in_scores) src = (int)desc_key_index(keys[r]);
+      int l = 0;
+      for (int q = 1; q < p.L_in; q++) if (src >= in_off[q]) l = q;
+      const int j = src - in_off[l];
+      bx = reinterpret_cast<const float4*>(boxes)[(size_t)l * p.P + j];
+      if (p.in_scores) sc = p.in_scores[((size_t)b * p.L_in + l) * p.P + j];
+      lvl = fpn_level(bx.x, bx.y, bx.z, bx.w, p.k_min, p.k_max) - p.k_min;
+    }
+    if (r < p.top_n) {
+      float* o = p.rois5 + ((size_t)b * p.top_n + r) * 5;
+      o[0] = (float)b; o[1] = bx.x; o[2] = bx.y; o[3] = bx.z; o[4] = bx.w;
+      p.roi_levels[(size_t)b * p.top_n + r] = lvl;
+      if (p.roi_scores) p.roi_scores[(size_t)b * p.top_n + r] = sc;
+    }
+    // position of r inside its level, in rank order (np.where(lvls == lvl)[0] is ascending, :123)
+    int my_before = 0;
+    for (int l = 0; l < nl_out; l++) {
+      const uint64_t mk = __ballot(lvl == l);
+      if (lane == 0) wave_cnt[l][wv] = __builtin_popcountll(mk);
+      if (lvl == l) my_before = __builtin_popcountll(mk & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    int pos_in_level = -1;
+    if (lvl >= 0) {
+      int base = lvl_run[lvl];
+      for (int q = 0; q < wv; q++) base += wave_cnt[lvl][q];
+      pos_in_level = base + my_before;
+    }
+    __syncthreads();
+    if (tid < nl_out) { int t = 0; for (int q = 0; q < kFpnThreads / 64; q++) t += wave_cnt[tid][q]; lvl_run[tid] += t; }
+    // stash (level, pos) for the second sweep in the key array's upper part is not possible (keys still needed), so
+    // write pos_in_level to idx_restore now and add the level offset below.
+    if (r < p.top_n) p.idx_restore[(size_t)b * p.top_n + r] = pos_in_level;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int acc = 0;
+    for (int l = 0; l < nl_out; l++) { lvl_off[l] = acc; acc += lvl_run[l]; p.level_counts[b * nl_out + l] = lvl_run[l]; }
+    lvl_off[nl_out] = acc;
+    p.n_out[b] = m;
+  }
+  __syncthreads();
+  for (int r = tid; r < m; r += kFpnThreads) {
+    const int lvl = p.roi_levels[(size_t)b * p.top_n + r];
+    const int dst = lvl_off[lvl] + p.idx_restore[(size_t)b * p.top_n + r];
+    p.idx_restore[(size_t)b * p.top_n + r] = dst;                  // :127 argsort(concat(idx_lvl)) == inverse permutation
+    const float* o = p.rois5 + ((size_t)b * p.top_n + r) * 5;
+    reinterpret_cast<float4*>(p.rois_by_level)[(size_t)b * p.top_n + dst] = make_float4(o[1], o[2], o[3], o[4]);
+  }
+}
+
+}  // namespace dtc
+
+DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_scores, const int32_t* in_counts, int batch,
+                                       int n_in_levels, int in_stride, int post_nms_top_n, int k_min, int k_max,
+                                       float* rois5, float* roi_scores, int32_t* roi_levels, int32_t* n_out,
+                                       float* rois_by_level, int32_t* level_counts, int32_t* idx_restore,
+                                       dtc_stream_t stream) {
+  if (batch < 0 || n_in_levels < 1 || n_in_levels > dtc::kFpnMaxLevels || in_stride < 1 || post_nms_top_n < 1 ||
+      k_max < k_min || k_max - k_min + 1 > dtc::kFpnMaxLevels)
+    return DTC_EINVAL;
+  if (batch == 0) return DTC_OK;
+  if (!in_boxes || !in_counts || !rois5 || !roi_levels || !n_out || !rois_by_level || !level_counts || !idx_restore)
+    return DTC_EINVAL;
+  const long long n_max = (long long)n_in_levels * in_stride;
+  if (in_scores && n_max > 16384) return DTC_EUNSUPPORTED;
+  dtc::FpnParams p;
+  p.in_boxes = in_boxes; p.in_scores = in_scores; p.in_counts = in_counts; p.L_in = n_in_levels; p.P = in_stride;
+  p.top_n = post_nms_top_n; p.k_min = k_min; p.k_max = k_max; p.rois5 = rois5; p.roi_scores = roi_scores;
+  p.roi_levels = roi_levels; p.n_out = n_out; p.rois_by_level = rois_by_level; p.level_counts = level_counts;
+  p.idx_restore = idx_restore;
+  const size_t smem = in_scores ? (size_t)dtc::next_pow2((int)n_max) * sizeof(uint64_t) : 16;
+  if (smem > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::fpn_collect_distribute_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess) return DTC_ELAUNCH;
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(dtc::fpn_collect_distribute_kernel, dim3(batch), dim3(dtc::kFpnThreads), smem,
+                     reinterpret_cast<hipStream_t>(stream), p);
+  DTC_CHECK_LAUNCH();
+  return DTC_OK;
+}

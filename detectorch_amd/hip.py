@@ -68,6 +68,15 @@ def lib():
     L.dtc_rpn_topk_decode.restype = i
     L.dtc_gather_kept.argtypes = [p, p, i, i, p, p, i, p, p, p]
     L.dtc_gather_kept.restype = i
+    ll = C.c_longlong
+    L.dtc_fpn_collect_distribute.argtypes = [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p]
+    L.dtc_fpn_collect_distribute.restype = i
+    L.dtc_postprocess_detections_workspace_bytes.argtypes = [i, i, i]
+    L.dtc_postprocess_detections_workspace_bytes.restype = sz
+    L.dtc_postprocess_detections.argtypes = [p, p, p, p, p, p, i, i, i, f, f, f, f, f, f, i, p, sz, p, p, p, p, i, p]
+    L.dtc_postprocess_detections.restype = i
+    L.dtc_mask_paste.argtypes = [p, p, i, i, p, p, p, i, i, f, i, p, ll, p, p, p, p, p]
+    L.dtc_mask_paste.restype = i
     _lib = L
     return L
 
@@ -257,3 +266,82 @@ def generate_proposals(cls_probs, bbox_preds, anchors, feat_strides, im_h, im_w,
     check(rc, "dtc_gather_kept")
     del alive
     return (out_boxes.view(B, nl, P, 4), out_scores.view(B, nl, P), kcnt.view(B, nl), pre_boxes, pre_scores, pre_counts)
+
+
+def fpn_collect_distribute(boxes, scores, counts, post_nms_top_n, k_min=2, k_max=5):
+    """dtc_fpn_collect_distribute.  boxes [B,L,P,4], scores [B,L,P] or None, counts int32 [B,L].
+    -> dict(rois5 [B,T,5], roi_scores, roi_levels [B,T], n_out [B], rois_by_level [B,T,4], level_counts [B,nl],
+            idx_restore [B,T])"""
+    dev = _require_cuda(boxes, scores, counts)
+    boxes = boxes.contiguous()
+    B, Lin, P = boxes.shape[0], boxes.shape[1], boxes.shape[2]
+    T = int(post_nms_top_n)
+    nl = k_max - k_min + 1
+    f32, i32 = torch.float32, torch.int32
+    out = dict(rois5=torch.empty((B, T, 5), dtype=f32, device=dev),
+               roi_scores=torch.empty((B, T), dtype=f32, device=dev) if scores is not None else None,
+               roi_levels=torch.empty((B, T), dtype=i32, device=dev), n_out=torch.empty((B,), dtype=i32, device=dev),
+               rois_by_level=torch.empty((B, T, 4), dtype=f32, device=dev),
+               level_counts=torch.empty((B, nl), dtype=i32, device=dev),
+               idx_restore=torch.empty((B, T), dtype=i32, device=dev))
+    if scores is not None:
+        scores = scores.contiguous()
+    counts = counts.to(i32).contiguous()
+    with torch.cuda.device(dev):
+        rc = lib().dtc_fpn_collect_distribute(boxes.data_ptr(), _ptr(scores), counts.data_ptr(), B, Lin, P, T, k_min,
+                                              k_max, out["rois5"].data_ptr(), _ptr(out["roi_scores"]),
+                                              out["roi_levels"].data_ptr(), out["n_out"].data_ptr(),
+                                              out["rois_by_level"].data_ptr(), out["level_counts"].data_ptr(),
+                                              out["idx_restore"].data_ptr(), stream_ptr(dev))
+    check(rc, "dtc_fpn_collect_distribute")
+    return out
+
+
+def postprocess_detections(rois5, n_rois, cls_score, bbox_pred, scaling_factor, im_size, weights=(10., 10., 5., 5.),
+                           score_thresh=0.05, nms_thresh=0.5, max_det=100, max_out=None, ws=None):
+    """dtc_postprocess_detections.  rois5 [B,R,5], cls_score [B,R,C], bbox_pred [B,R,4C], scaling_factor [B], im_size [B,2].
+    -> (dets [B,max_out,6], det_roi [B,max_out], det_rois_scaled [B,max_out,4], det_count [B])"""
+    dev = _require_cuda(rois5, n_rois, cls_score, bbox_pred, scaling_factor, im_size)
+    B, R, ncls = cls_score.shape
+    if max_out is None:
+        max_out = 128 if max_det > 0 else R * (ncls - 1)
+    L_ = lib()
+    need = L_.dtc_postprocess_detections_workspace_bytes(B, R, ncls)
+    if ws is None or ws.numel() < need:
+        ws = workspace(need, dev)
+    f32, i32 = torch.float32, torch.int32
+    dets = torch.zeros((B, max_out, 6), dtype=f32, device=dev)
+    det_roi = torch.zeros((B, max_out), dtype=i32, device=dev)
+    det_scaled = torch.zeros((B, max_out, 4), dtype=f32, device=dev)
+    det_count = torch.empty((B,), dtype=i32, device=dev)
+    rois5, cls_score, bbox_pred = rois5.contiguous(), cls_score.contiguous(), bbox_pred.contiguous()
+    scaling_factor, im_size = scaling_factor.to(f32).contiguous(), im_size.to(f32).contiguous()
+    with torch.cuda.device(dev):
+        rc = L_.dtc_postprocess_detections(rois5.data_ptr(), _ptr(n_rois), cls_score.data_ptr(), bbox_pred.data_ptr(),
+                                           scaling_factor.data_ptr(), im_size.data_ptr(), B, R, ncls,
+                                           *[float(w) for w in weights], float(score_thresh), float(nms_thresh),
+                                           int(max_det), ws.data_ptr(), ws.numel(), dets.data_ptr(), det_roi.data_ptr(),
+                                           det_scaled.data_ptr(), det_count.data_ptr(), int(max_out), stream_ptr(dev))
+    check(rc, "dtc_postprocess_detections")
+    return dets, det_roi, det_scaled, det_count
+
+
+def mask_paste(masks, dets, det_count, im_size, M, per_image_capacity, mask_index=None, thresh=0.5, cls_specific=True):
+    """dtc_mask_paste -> dict(crops uint8 [B,cap], boxes int32 [B,D,4], rects int32 [B,D,4], offsets int64 [B,D], bytes int64 [B])"""
+    dev = _require_cuda(masks, dets, det_count, im_size, mask_index)
+    masks, dets = masks.contiguous(), dets.contiguous()
+    B, D = dets.shape[0], dets.shape[1]
+    cap = int(per_image_capacity)
+    out = dict(crops=torch.empty((B, max(cap, 1)), dtype=torch.uint8, device=dev),
+               boxes=torch.zeros((B, D, 4), dtype=torch.int32, device=dev),
+               rects=torch.zeros((B, D, 4), dtype=torch.int32, device=dev),
+               offsets=torch.zeros((B, D), dtype=torch.int64, device=dev),
+               bytes=torch.zeros((B,), dtype=torch.int64, device=dev))
+    with torch.cuda.device(dev):
+        rc = lib().dtc_mask_paste(masks.data_ptr(), _ptr(mask_index), masks.shape[1], int(M), dets.data_ptr(),
+                                  det_count.data_ptr(), im_size.to(torch.float32).contiguous().data_ptr(), B, D,
+                                  float(thresh), 1 if cls_specific else 0, out["crops"].data_ptr(), cap,
+                                  out["boxes"].data_ptr(), out["rects"].data_ptr(), out["offsets"].data_ptr(),
+                                  out["bytes"].data_ptr(), stream_ptr(dev))
+    check(rc, "dtc_mask_paste")
+    return out

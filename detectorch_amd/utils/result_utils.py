@@ -1,0 +1,178 @@
+"""Detection post-processing -- same names / arguments / return layout as the reference's lib/utils/result_utils.py, with
+the arithmetic done by the HIP kernels (detectorch_amd/csrc/detections.hip, nms.hip, mask_paste.hip).
+
+    postprocess_output              result_utils.py:76-94
+    box_results_with_nms_and_limit  result_utils.py:96-168   (hard NMS and Soft-NMS; bbox voting is not on the hot path)
+    segm_results                    result_utils.py:170-228  (RLE: pycocotools if importable, else the numpy encoder below)
+    empty_results / extend_results  result_utils.py:32-60
+"""
+import numpy as np
+import torch
+
+from .. import hip
+from . import boxes as box_utils
+
+
+def to_np(x):
+    if isinstance(x, np.ndarray):
+        return x
+    return x.detach().cpu().numpy()
+
+
+def empty_results(num_classes, num_images):
+    all_boxes = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    all_segms = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    all_keyps = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    return all_boxes, all_segms, all_keyps
+
+
+def extend_results(index, all_res, im_res):
+    for cls_idx in range(1, len(im_res)):
+        all_res[cls_idx][index] = im_res[cls_idx]
+
+
+def _dev(*xs):
+    for x in xs:
+        if torch.is_tensor(x) and x.is_cuda:
+            return x.device
+    if not torch.cuda.is_available():
+        raise RuntimeError("detectorch_amd needs the MI355X HIP path (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _t(x, dev):
+    if torch.is_tensor(x):
+        return x.detach().to(device=dev, dtype=torch.float32)
+    return torch.as_tensor(np.asarray(x, dtype=np.float32), device=dev)
+
+
+def _split_by_class(dets, n, num_classes):
+    dets = dets[:n]
+    cls = dets[:, 5].astype(np.int64)
+    cls_boxes = [[] for _ in range(num_classes)]
+    for j in range(1, num_classes):
+        cls_boxes[j] = np.ascontiguousarray(dets[cls == j, :5])
+    return dets[:, 4].copy(), np.ascontiguousarray(dets[:, :4]), cls_boxes
+
+
+def postprocess_output(rois, scaling_factor, im_size, class_scores, bbox_deltas, bbox_reg_weights=(10.0, 10.0, 5.0, 5.0)):
+    """result_utils.py:76-94 -> (scores_final [D], boxes_final [D,4], boxes_per_class list[81] of [d_j,5])."""
+    dev = _dev(rois, class_scores, bbox_deltas)
+    rois = _t(rois, dev)
+    if rois.dim() == 3:
+        rois = rois.squeeze(0)
+    R = rois.shape[0]
+    cls = _t(class_scores, dev).reshape(1, R, -1)
+    dl = _t(bbox_deltas, dev).reshape(1, R, -1)
+    n_cls = cls.shape[2]
+    rois5 = torch.cat([torch.zeros((R, 1), device=dev), rois[:, -4:]], 1).reshape(1, R, 5)
+    sf = _t(scaling_factor, dev).reshape(-1)[:1]
+    sz = _t(im_size, dev).reshape(-1)[:2].reshape(1, 2)
+    dets, _, _, cnt = hip.postprocess_detections(rois5, None, cls, dl, sf, sz, weights=bbox_reg_weights,
+                                                 max_out=max(R * (n_cls - 1), 1) if R * (n_cls - 1) <= 4096 else 4096)
+    n = int(cnt[0].item())
+    if n > dets.shape[1]:
+        dets, _, _, cnt = hip.postprocess_detections(rois5, None, cls, dl, sf, sz, weights=bbox_reg_weights, max_out=n)
+    return _split_by_class(dets[0].cpu().numpy(), n, n_cls)
+
+
+def box_results_with_nms_and_limit(scores, boxes, num_classes=81, score_thresh=0.05, overlap_thresh=0.5,
+                                   do_soft_nms=False, soft_nms_sigma=0.5, soft_nms_method='linear', do_bbox_vote=False,
+                                   bbox_vote_thresh=0.8, bbox_vote_method='ID', max_detections_per_img=100):
+    """result_utils.py:96-168 on already decoded+clipped boxes [R,4*num_classes] (numpy in / numpy out)."""
+    if do_bbox_vote:
+        raise NotImplementedError("bbox voting (lib/utils/boxes.py:280-329) is off by default and out of the hot-path scope")
+    scores = np.ascontiguousarray(scores, np.float32)
+    boxes = np.ascontiguousarray(boxes, np.float32)
+    cls_boxes = [[] for _ in range(num_classes)]
+    for j in range(1, num_classes):
+        inds = np.where(scores[:, j] > score_thresh)[0]
+        dets_j = np.hstack((boxes[inds, j * 4:(j + 1) * 4], scores[inds, j][:, np.newaxis])).astype(np.float32, copy=False)
+        if do_soft_nms:
+            nms_dets, _ = box_utils.soft_nms(dets_j, sigma=soft_nms_sigma, overlap_thresh=overlap_thresh,
+                                             score_thresh=0.0001, method=soft_nms_method)
+        else:
+            keep = box_utils.nms(dets_j, overlap_thresh)
+            nms_dets = dets_j[keep, :]
+        cls_boxes[j] = nms_dets
+    if max_detections_per_img > 0:
+        image_scores = np.hstack([cls_boxes[j][:, -1] for j in range(1, num_classes)])
+        if len(image_scores) > max_detections_per_img:
+            image_thresh = np.sort(image_scores)[-max_detections_per_img]
+            for j in range(1, num_classes):
+                keep = np.where(cls_boxes[j][:, -1] >= image_thresh)[0]
+                cls_boxes[j] = cls_boxes[j][keep, :]
+    im_results = np.vstack([cls_boxes[j] for j in range(1, num_classes)])
+    return im_results[:, -1], im_results[:, :-1], cls_boxes
+
+
+# ---- COCO RLE (the wire format pycocotools.mask.encode produces); used only when pycocotools is not importable -------
+def _rle_counts_to_string(cnts):
+    out = []
+    for i, c in enumerate(cnts):
+        x = int(c)
+        if i > 2:
+            x -= int(cnts[i - 2])
+        more = True
+        while more:
+            ch = x & 0x1f
+            x >>= 5
+            more = (x != -1) if (ch & 0x10) else (x != 0)
+            if more:
+                ch |= 0x20
+            out.append(chr(ch + 48))
+    return "".join(out)
+
+
+def rle_encode(mask):
+    """mask [h,w] uint8 -> {'size': [h,w], 'counts': str}: column-major run lengths starting with a run of zeros."""
+    h, w = mask.shape
+    flat = np.asarray(mask, np.uint8).reshape(-1, order='F')
+    change = np.flatnonzero(np.diff(flat)) + 1
+    runs = np.diff(np.concatenate([[0], change, [flat.size]]))
+    if flat.size and flat[0] == 1:
+        runs = np.concatenate([[0], runs])
+    return {'size': [int(h), int(w)], 'counts': _rle_counts_to_string(runs.tolist())}
+
+
+def segm_results(cls_boxes, masks, ref_boxes, im_h, im_w, num_classes=81, M=14, cls_specific_mask=True,
+                 thresh_binarize=0.5):
+    """result_utils.py:170-228.  masks may be a CUDA tensor (preferred: nothing but the crops leaves the GPU) or ndarray."""
+    dev = _dev(masks)
+    masks_t = masks if torch.is_tensor(masks) else torch.from_numpy(np.ascontiguousarray(masks, np.float32))
+    masks_t = masks_t.to(device=dev, dtype=torch.float32)
+    ref = np.ascontiguousarray(ref_boxes, np.float32)
+    D = ref.shape[0]
+    cls_of = np.concatenate([np.full(len(cls_boxes[j]), j, np.float32) for j in range(1, num_classes)]) if D else np.zeros(0, np.float32)
+    assert cls_of.shape[0] == masks_t.shape[0] == D                  # :227
+    cls_segms = [[] for _ in range(num_classes)]
+    if D == 0:
+        return cls_segms
+    dets = np.zeros((1, D, 6), np.float32)
+    dets[0, :, :4] = ref
+    dets[0, :, 5] = cls_of
+    cap = int(im_h) * int(im_w) * D
+    out = hip.mask_paste(masks_t, torch.from_numpy(dets).to(dev), torch.tensor([D], dtype=torch.int32, device=dev),
+                         torch.tensor([[float(im_h), float(im_w)]], device=dev), M, cap,
+                         mask_index=torch.arange(D, dtype=torch.int32, device=dev).reshape(1, D), thresh=thresh_binarize,
+                         cls_specific=cls_specific_mask)
+    nbytes = int(out["bytes"][0].item())
+    crops = out["crops"][0, :nbytes].cpu().numpy()
+    rects = out["rects"][0].cpu().numpy()
+    offs = out["offsets"][0].cpu().numpy()
+    try:
+        import pycocotools.mask as mask_util
+    except ImportError:
+        mask_util = None
+    for d in range(D):
+        x0, y0, x1, y1 = rects[d]
+        im_mask = np.zeros((int(im_h), int(im_w)), dtype=np.uint8)
+        if x1 > x0 and y1 > y0:
+            im_mask[y0:y1, x0:x1] = crops[offs[d]:offs[d] + (x1 - x0) * (y1 - y0)].reshape(y1 - y0, x1 - x0)
+        if mask_util is not None:
+            rle = mask_util.encode(np.array(im_mask[:, :, np.newaxis], order='F'))[0]
+            rle['counts'] = rle['counts'].decode()
+        else:
+            rle = rle_encode(im_mask)
+        cls_segms[int(cls_of[d])].append(rle)
+    return cls_segms

@@ -128,6 +128,60 @@ int dtc_gather_kept(const float* sorted_boxes, const float* sorted_scores, int n
                     const int32_t* keep_count, int keep_stride, float* out_boxes, float* out_scores,
                     dtc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * A7  FPN collect + distribute
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* collect() + distribute() of lib/model/collect_and_distribute_fpn_rpn_proposals.py:84-128 and
+ * map_rois_to_fpn_levels of lib/utils/multilevel_rois.py:41-53, one workgroup per image.
+ *   in_boxes float32 [B, n_in_levels, in_stride, 4], in_scores float32 [B, n_in_levels, in_stride] (post-NMS RPN
+ *   proposals per level, rows >= in_counts[b,l] ignored).  in_scores == NULL: no sort, the rows are taken in the given
+ *   order (add_multilevel_rois_for_test, lib/utils/multilevel_rois.py:19-39 -- the mask branch).
+ * Outputs (post_nms_top_n rows per image; rows >= n_out[b] are padding with level -1):
+ *   rois5 [B,topN,5] = (b,x1,y1,x2,y2) in collected (score) order; roi_scores [B,topN] (nullable);
+ *   roi_levels int32 [B,topN] = level - k_min; n_out int32 [B];
+ *   rois_by_level [B,topN,4] + level_counts int32 [B,k_max-k_min+1] = the reference's per-level lists, concatenated;
+ *   idx_restore int32 [B,topN] = the reference's rois_idx_restore (:127). */
+int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_scores, const int32_t* in_counts, int batch,
+                               int n_in_levels, int in_stride, int post_nms_top_n, int k_min, int k_max, float* rois5,
+                               float* roi_scores, int32_t* roi_levels, int32_t* n_out, float* rois_by_level,
+                               int32_t* level_counts, int32_t* idx_restore, dtc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * A8  Detection post-processing
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* postprocess_output + box_results_with_nms_and_limit (hard NMS) of lib/utils/result_utils.py:76-168 for a batch.
+ *   rois5 [B,R,5] (network-scale rois, column 0 ignored), n_rois int32 [B] (NULL: R), cls_score [B,R,n_cls] (softmax),
+ *   bbox_pred [B,R,4*n_cls], scaling_factor float32 [B], im_size float32 [B,2] = original (h,w).
+ *   (wx,wy,ww,wh) = bbox_reg_weights (10,10,5,5); score_thresh 0.05; nms_thresh 0.5; max_det 100 (0: unlimited).
+ * Outputs: dets [B,max_out,6] = (x1,y1,x2,y2,score,class) ordered by class then by roi index (== np.vstack(cls_boxes),
+ * :165); det_roi int32 [B,max_out] source roi; det_rois_scaled [B,max_out,4] = boxes * scaling_factor (nullable; the
+ * rois of the mask branch, eval_mask_FPN.ipynb:249); det_count int32 [B] = true number (can exceed max_det on score
+ * ties like the reference, :161; rows beyond max_out are dropped -- compare det_count with max_out). R <= 4096. */
+size_t dtc_postprocess_detections_workspace_bytes(int batch, int max_rois, int n_cls);
+int dtc_postprocess_detections(const float* rois5, const int32_t* n_rois, const float* cls_score, const float* bbox_pred,
+                               const float* scaling_factor, const float* im_size, int batch, int max_rois, int n_cls,
+                               float wx, float wy, float ww, float wh, float score_thresh, float nms_thresh, int max_det,
+                               void* workspace, size_t workspace_bytes, float* dets, int32_t* det_roi,
+                               float* det_rois_scaled, int32_t* det_count, int max_out, dtc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * A9  Mask resize + binarise (+ paste geometry)
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* The per-detection body of segm_results, lib/utils/result_utils.py:182-214 (everything but the RLE encode).
+ *   masks float32 [n_masks,n_cls,M,M] (mask-head output); mask_index int32 [B,max_out] row of each detection in masks
+ *   (NULL: b*max_out + d); dets [B,max_out,6] / det_count [B] as produced above; im_size [B,2] original (h,w).
+ * Outputs: mask_boxes int32 [B,max_out,4] expanded+truncated ref box (:183-184); mask_rects int32 [B,max_out,4] paste
+ * rectangle (x_0,y_0,x_1,y_1) (:204-207); crops uint8 [B,per_image_capacity]: for detection d the binarised resized mask
+ * restricted to its paste rectangle, row-major, at byte mask_offsets[b,d] of image b's region; mask_bytes int64 [B] =
+ * bytes image b needs (if > per_image_capacity the detections that did not fit were skipped). */
+int dtc_mask_paste(const float* masks, const int32_t* mask_index, int n_cls, int M, const float* dets,
+                   const int32_t* det_count, const float* im_size, int batch, int max_out, float thresh_binarize,
+                   int cls_specific_mask, uint8_t* crops, long long per_image_capacity, int32_t* mask_boxes,
+                   int32_t* mask_rects, long long* mask_offsets, long long* mask_bytes, dtc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

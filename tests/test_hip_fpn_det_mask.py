@@ -1,0 +1,199 @@
+"""A7 / A8 / A9 parity on the GPU: FPN collect+distribute, detection post-processing, mask resize/binarise.  -m gpu.
+Indices, level ids, class ids, counts, restore permutations, binary masks: bit-exact.  Box coordinates: bit-exact vs the
+oracle, 1e-4 / 1 ulp vs the reference-generated golden vectors (numpy exp)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, ulp_close
+from detectorch_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from detectorch_amd import hip as h
+    h.lib()
+    return h
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---------------------------------------------------------------- A7 ------------------------------------------------
+@pytest.mark.parametrize("pre", ["", "big_"])
+def test_collect_distribute_golden_module(hip, pre):
+    from detectorch_amd.model.collect_and_distribute_fpn_rpn_proposals import CollectAndDistributeFpnRpnProposals
+    g = golden("collect_distribute")
+    cd = CollectAndDistributeFpnRpnProposals(spatial_scales=list(synth.FPN_ROI_SCALES))
+    distr, restore = cd([cu(g[pre + "rois%d" % l]) for l in range(5)], [cu(g[pre + "scores%d" % l]) for l in range(5)])
+    assert isinstance(restore, np.ndarray) and len(distr) == 4
+    for i in range(4):
+        assert np.array_equal(distr[i].cpu().numpy(), g[pre + "distr%d" % i])
+    assert np.array_equal(restore, g[pre + "restore"])
+
+
+def test_level_boundaries_golden_and_blobs(hip):
+    from detectorch_amd.utils.multilevel_rois import add_multilevel_rois_for_test, map_rois_to_fpn_levels
+    g = golden("collect_distribute")
+    assert np.array_equal(map_rois_to_fpn_levels(g["lvl_boxes"], 2, 5).astype(np.int32), g["lvl_out"])
+    blobs = add_multilevel_rois_for_test({"rois": g["lvl_boxes"]}, "rois")
+    assert sorted(k for k in blobs if "fpn" in k) == ["rois_fpn2", "rois_fpn3", "rois_fpn4", "rois_fpn5"]
+    for lvl in range(2, 6):
+        assert np.array_equal(blobs["rois_fpn%d" % lvl], g["lvl_boxes"][g["lvl_out"] == lvl])
+    assert blobs["rois_idx_restore_int32"].dtype == np.int32
+
+
+def test_collect_distribute_batched_vs_oracle(hip, oracle):
+    B, L, P = 3, 5, 1000
+    rs = synth.rng(4, 50)
+    boxes = np.zeros((B, L, P, 4), np.float32)
+    scores = np.zeros((B, L, P), np.float32)
+    counts = rs.randint(0, P + 1, (B, L)).astype(np.int32)
+    counts[1] = [P, P, P, P, 819]
+    counts[2] = [3, 0, 0, 1, 0]                    # fewer rois than top-N, empty levels
+    for b in range(B):
+        sc = synth.dedupe_scores(rs.uniform(0, 1, L * P).astype(np.float32)).reshape(L, P)
+        for l in range(L):
+            boxes[b, l, :counts[b, l]] = synth.make_rois(rs, counts[b, l])
+            scores[b, l] = sc[l]
+    res = hip.fpn_collect_distribute(cu(boxes), cu(scores), cu(counts), 1000, 2, 5)
+    for b in range(B):
+        rc = np.concatenate([boxes[b, l, :counts[b, l]] for l in range(L)])
+        sc = np.concatenate([scores[b, l, :counts[b, l]] for l in range(L)])
+        top, tsc, _ = oracle.collect(rc, sc, 1000)
+        outs, restore, lv = oracle.distribute(top, 2, 5)
+        n = int(res["n_out"][b])
+        assert n == top.shape[0]
+        assert np.array_equal(res["rois5"][b, :n, 1:].cpu().numpy(), top)
+        assert np.all(res["rois5"][b, :n, 0].cpu().numpy() == b)
+        assert np.array_equal(res["roi_scores"][b, :n].cpu().numpy(), tsc)
+        assert np.array_equal(res["roi_levels"][b, :n].cpu().numpy(), lv - 2)
+        assert np.all(res["roi_levels"][b, n:].cpu().numpy() == -1)
+        assert np.array_equal(res["idx_restore"][b, :n].cpu().numpy(), restore)
+        assert np.array_equal(res["level_counts"][b].cpu().numpy(), [o.shape[0] for o in outs])
+        assert np.array_equal(res["rois_by_level"][b, :n].cpu().numpy(), np.concatenate(outs) if n else np.zeros((0, 4)))
+
+
+# ---------------------------------------------------------------- A8 ------------------------------------------------
+def test_postprocess_golden_module(hip):
+    from detectorch_amd.utils import result_utils
+    g = golden("postprocess")
+    scores_final, boxes_final, cls_boxes = result_utils.postprocess_output(
+        cu(g["rois"]), float(g["sf"][0]), torch.from_numpy(g["im_size"]), cu(g["cls"]), cu(g["deltas"]))
+    assert len(cls_boxes) == 81 and scores_final.shape[0] >= 100
+    assert np.array_equal(scores_final, g["scores_final"])
+    assert ulp_close(boxes_final, g["boxes_final"])
+    cls_id = np.concatenate([np.full(len(cls_boxes[j]), j, np.int32) for j in range(1, 81)])
+    assert np.array_equal(cls_id, g["cls_id"])
+
+
+def test_box_results_with_nms_and_limit_golden(hip):
+    from detectorch_amd.utils import result_utils
+    g = golden("postprocess")
+    for limit, pre in ((100, ""), (0, "nolimit_")):
+        sc, bx, cb = result_utils.box_results_with_nms_and_limit(g["cls"], g["pred_clipped"].copy(),
+                                                                 max_detections_per_img=limit)
+        ref_s = g["scores_final"] if limit else g["nolimit_scores"]
+        ref_b = g["boxes_final"] if limit else g["nolimit_boxes"]
+        assert np.array_equal(sc, ref_s) and np.array_equal(bx, ref_b)
+
+
+@pytest.mark.parametrize("R,max_det", [(1000, 100), (1000, 0), (300, 100), (2000, 100)])
+def test_postprocess_batched_vs_oracle(hip, oracle, R, max_det):
+    B = 2
+    rs = synth.rng(5, R + max_det)
+    rois = np.stack([synth.make_rois(rs, R) for _ in range(B)])
+    rois5 = np.concatenate([np.zeros((B, R, 1), np.float32), rois], 2)
+    cls = np.zeros((B, R, 81), np.float32)
+    dl = np.zeros((B, R, 324), np.float32)
+    for b in range(B):
+        cls[b], dl[b] = synth.make_head_outputs(rs, R)
+    n_rois = np.array([R, R - 37], np.int32)
+    sf = np.array([1.6, 1.3333334], np.float32)
+    im = np.array([[500, 833], [600, 900]], np.float32)
+    cap = 4096
+    dets, roi, scaled, cnt = hip.postprocess_detections(cu(rois5), cu(n_rois), cu(cls), cu(dl), cu(sf), cu(im),
+                                                        max_det=max_det, max_out=cap)
+    for b in range(B):
+        n = n_rois[b]
+        rd, rr = oracle.postprocess_detections(rois[b, :n], sf[b], im[b], cls[b, :n], dl[b, :n], max_det=max_det)
+        c = int(cnt[b])
+        assert c == rd.shape[0]
+        c = min(c, cap)
+        assert np.array_equal(dets[b, :c].cpu().numpy(), rd[:c])       # boxes bit-exact vs the oracle
+        assert np.array_equal(roi[b, :c].cpu().numpy(), rr[:c])
+        assert np.array_equal(scaled[b, :c].cpu().numpy(), rd[:c, :4] * sf[b])
+
+
+# ---------------------------------------------------------------- A9 ------------------------------------------------
+@pytest.mark.parametrize("M", [14, 28])
+def test_mask_geometry_golden(hip, M):
+    g = golden("mask_geometry")
+    rb = g["ref_boxes"]
+    D = rb.shape[0]
+    dets = np.zeros((1, D, 6), np.float32)
+    dets[0, :, :4] = rb
+    dets[0, :, 5] = 1
+    masks = torch.zeros((D, 2, M, M), device="cuda")
+    out = hip.mask_paste(masks, cu(dets), cu(np.array([D], np.int32)), cu(np.array([[500., 833.]], np.float32)), M,
+                         500 * 833 * 8)
+    assert np.array_equal(out["boxes"][0].cpu().numpy(), g["exp_int_M%d" % M])
+
+
+def test_mask_paste_vs_oracle_and_segm_results(hip, oracle):
+    from detectorch_amd.utils import result_utils
+    rs = synth.rng(6, 3)
+    M, D, im_h, im_w = 28, 40, 500, 833
+    rb = synth.make_rois(rs, D, im_h=im_h, im_w=im_w, min_side=6, max_side=450)
+    rb[0] = [-20, -30, 40, 50]                 # sticks out of the image: paste clipping
+    rb[1] = [800, 450, 900, 520]
+    rb[2] = [100, 100, 100.4, 100.4]           # degenerate -> 1x1 resize target
+    cls = rs.randint(1, 81, D)
+    order = np.argsort(cls, kind="stable")
+    rb, cls = rb[order], cls[order]
+    masks = synth.make_masks(rs, D, 81, M)
+    cls_boxes = [[] for _ in range(81)]
+    for j in range(1, 81):
+        cls_boxes[j] = np.hstack([rb[cls == j], np.ones((int((cls == j).sum()), 1), np.float32)])
+    segms = result_utils.segm_results(cls_boxes, torch.from_numpy(masks).cuda(), rb, im_h, im_w, M=M)
+    assert sum(len(s) for s in segms) == D
+    # decode our RLE back and compare with the oracle's full-frame paste
+    def rle_decode(rle):
+        h, w = rle['size']
+        s, cnts, p = rle['counts'], [], 0
+        while p < len(s):
+            x, k, more = 0, 0, True
+            while more:
+                c = ord(s[p]) - 48
+                x |= (c & 0x1f) << (5 * k)
+                more = bool(c & 0x20)
+                p += 1; k += 1
+                if not more and (c & 0x10):
+                    x |= -1 << (5 * k)
+            if len(cnts) > 2:
+                x += cnts[-2]
+            cnts.append(x)
+        flat = np.zeros(h * w, np.uint8)
+        pos, v = 0, 0
+        for c in cnts:
+            flat[pos:pos + c] = v
+            pos += c; v = 1 - v
+        return flat.reshape((h, w), order='F')
+    seen = {j: 0 for j in range(81)}
+    n_ones = 0
+    for d in range(D):
+        j = int(cls[d])
+        box, crop = oracle.mask_resize_binarize(masks[d, j], rb[d])
+        ref = np.zeros((im_h, im_w), np.uint8)
+        x0, x1 = max(box[0], 0), min(box[2] + 1, im_w)
+        y0, y1 = max(box[1], 0), min(box[3] + 1, im_h)
+        if x1 > x0 and y1 > y0:
+            ref[y0:y1, x0:x1] = crop[y0 - box[1]:y1 - box[1], x0 - box[0]:x1 - box[0]]
+        got = rle_decode(segms[j][seen[j]])
+        seen[j] += 1
+        assert np.array_equal(got, ref), d
+        n_ones += int(ref.sum())
+    assert n_ones > 1000
