@@ -61,6 +61,13 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_general(RoiAli
   const int r = blockIdx.x;
   const int c0 = blockIdx.y * p.ch_tile;
   const int lvl = p.roi_levels ? p.roi_levels[r] : 0;
+  if (lvl < 0 || lvl >= p.n_levels) {  // padding row of a fixed-shape batch (fpn.hip emits level -1): defined output
+    const int bins0 = p.pooled_h * p.pooled_w;
+    const int nc0 = min(p.ch_tile, p.channels - c0);
+    TOut* o0 = reinterpret_cast<TOut*>(p.out) + ((size_t)r * p.channels + c0) * bins0;
+    for (int o = threadIdx.x; o < nc0 * bins0; o += kRoiAlignThreads) o0[o] = from_f32<TOut>(0.f);
+    return;
+  }
   const dtc_feat_level L = p.lv[lvl];
   const float* roi = p.rois + (size_t)r * p.roi_cols;
   int b = 0;

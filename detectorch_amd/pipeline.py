@@ -1,0 +1,185 @@
+"""Device-resident region-proposal hot path for a BATCH of images (Mask R-CNN FPN flavour, BASELINE cfg3/cfg4).
+
+This is the MI355X-first composition of the kernels behind the reference-shaped modules: everything the reference does
+between the RPN-head outputs and the box/mask-head GEMMs, and after them, for B images at once, with zero host round
+trips and (optionally) replayed from one hipGraph:
+
+    RPN outputs (5 levels) --[rpn_topk_decode, nms_sorted, gather]--> per-level proposals      generate_proposals.py:31-122
+      --[fpn_collect_distribute]--> rois5 [B,1000,5] + level ids                               collect_and_distribute...py:84-128
+      --[roi_align 7x7, all levels, one launch]--> box-head features [B*1000,256,7,7]          detector.py:263-270
+      (box head fc6/fc7/cls/bbox: hipBLASLt GEMMs, not part of the hot path -- supplied by the caller / synthetic)
+      --[postprocess_detections]--> dets [B,128,6]                                             result_utils.py:76-168
+      --[fpn_collect_distribute (no sort)]--> mask-branch level ids                            multilevel_rois.py:19-39
+      --[roi_align 14x14]--> mask-head features [B*128,256,14,14]                              detector.py:99-106
+      (mask head convs: MIOpen, not part of the hot path -- supplied by the caller / synthetic)
+      --[mask_paste]--> binarised crops                                                        result_utils.py:170-214
+"""
+import numpy as np
+import torch
+
+from . import hip, synth
+from .utils.generate_anchors import generate_anchors
+
+
+class FpnRegionPath:
+    def __init__(self, batch, device, channels=256, n_cls=81, pre_nms_top_n=1000, post_nms_top_n=1000,
+                 collect_top_n=1000, rpn_nms_thresh=0.7, max_det=100, max_out=128, mask_res=28,
+                 box_pooled=7, mask_pooled=14, sampling_ratio=2, pad_h=synth.FPN_PAD_H, pad_w=synth.FPN_PAD_W,
+                 feat_dtype=torch.float32, crop_capacity=8 << 20):
+        self.B, self.dev = batch, device
+        self.C, self.n_cls = channels, n_cls
+        self.pre, self.post, self.top_n = pre_nms_top_n, post_nms_top_n, collect_top_n
+        self.rpn_thresh, self.max_det, self.max_out, self.M = rpn_nms_thresh, max_det, max_out, mask_res
+        self.box_p, self.mask_p, self.sr = box_pooled, mask_pooled, sampling_ratio
+        self.pad_h, self.pad_w = pad_h, pad_w
+        self.shapes = synth.fpn_level_shapes(pad_h, pad_w)
+        self.strides = [float(s) for s in synth.FPN_STRIDES]
+        self.anchors = [generate_anchors(stride=self.strides[l], sizes=(32.0 * 2 ** l,), aspect_ratios=(0.5, 1, 2))
+                        for l in range(5)]                         # detector.py:203-205
+        self.roi_scales = list(synth.FPN_ROI_SCALES)
+        self.feat_dtype = feat_dtype
+        self.crop_capacity = crop_capacity
+        self.graph = None
+        self._alloc()
+
+    # ---- buffers (allocated once; the step itself never allocates) ---------------------------------------------------
+    def _alloc(self):
+        B, dev, f32, i32 = self.B, self.dev, torch.float32, torch.int32
+        L = hip.lib()
+        S = B * 5
+        self.kmax = self.pre
+        e = lambda *shape, dtype=f32: torch.empty(shape, dtype=dtype, device=dev)
+        self.pre_boxes, self.pre_scores, self.pre_counts = e(S, self.kmax, 4), e(S, self.kmax), e(S, dtype=i32)
+        self.P = min(self.post, self.kmax)
+        self.keep, self.keep_cnt = e(S, self.P, dtype=i32), e(S, dtype=i32)
+        self.prop_boxes, self.prop_scores = torch.zeros((S, self.P, 4), device=dev), torch.zeros((S, self.P), device=dev)
+        self.nms_ws = hip.workspace(L.dtc_nms_sorted_workspace_bytes(S, self.kmax), dev)
+        T = self.top_n
+        self.rois5, self.roi_scores = e(B, T, 5), e(B, T)
+        self.roi_levels, self.n_rois = e(B, T, dtype=i32), e(B, dtype=i32)
+        self.rois_by_level, self.level_counts, self.idx_restore = e(B, T, 4), e(B, 4, dtype=i32), e(B, T, dtype=i32)
+        self.box_feats = e(B * T, self.C, self.box_p, self.box_p, dtype=self.feat_dtype)
+        D = self.max_out
+        self.dets, self.det_roi = torch.zeros((B, D, 6), device=dev), torch.zeros((B, D), dtype=i32, device=dev)
+        self.det_scaled, self.det_count = torch.zeros((B, D, 4), device=dev), e(B, dtype=i32)
+        self.det_ws = hip.workspace(L.dtc_postprocess_detections_workspace_bytes(B, T, self.n_cls), dev)
+        self.det_count_c = e(B, 1, dtype=i32)
+        self.m_rois5, self.m_levels, self.m_n = e(B, D, 5), e(B, D, dtype=i32), e(B, dtype=i32)
+        self.m_by_level, self.m_level_counts, self.m_restore = e(B, D, 4), e(B, 4, dtype=i32), e(B, D, dtype=i32)
+        self.mask_feats = e(B * D, self.C, self.mask_p, self.mask_p, dtype=self.feat_dtype)
+        self.crops = torch.empty((B, self.crop_capacity), dtype=torch.uint8, device=dev)
+        self.mask_boxes, self.mask_rects = torch.zeros((B, D, 4), dtype=i32, device=dev), torch.zeros((B, D, 4), dtype=i32, device=dev)
+        self.mask_offsets, self.mask_bytes = torch.zeros((B, D), dtype=torch.int64, device=dev), torch.zeros((B,), dtype=torch.int64, device=dev)
+
+    def bind(self, rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, scaling_factor, im_size):
+        """Attach the (device) inputs of one batch.  Pointers are baked into the launch descriptors (and the graph), so
+        new data is COPIED into these tensors between steps, like any static-shape serving loop."""
+        B = self.B
+        self.rpn_cls, self.rpn_bbox, self.feats = rpn_cls, rpn_bbox, feats
+        self.cls_score, self.bbox_pred, self.masks = cls_score, bbox_pred, masks
+        self.sf, self.im_size = scaling_factor, im_size
+        self.rpn_lv, self._alive = hip.make_rpn_levels(rpn_cls, rpn_bbox, self.anchors, self.strides, [self.pre] * 5)
+        self.rpn_ws = hip.workspace(hip.lib().dtc_rpn_topk_decode_workspace_bytes(self.rpn_lv, 5, B, self.kmax), self.dev)
+        self.feat_lv, _, _ = hip.make_levels(feats, self.roi_scales)
+        self.feat_code = hip._dtype_code(feats[0].dtype)
+        self.out_code = hip._dtype_code(self.feat_dtype)
+        self.graph = None
+
+    # ---- one pass of the hot path over the bound batch ---------------------------------------------------------------
+    def _launch(self):
+        L, B, st, ck = hip.lib(), self.B, hip.stream_ptr(self.dev), hip.check
+        S, T, D = B * 5, self.top_n, self.max_out
+        ck(L.dtc_rpn_topk_decode(self.rpn_lv, 5, B, float(self.pad_h), float(self.pad_w), 0.0, self.rpn_ws.data_ptr(),
+                                 self.rpn_ws.numel(), self.pre_boxes.data_ptr(), self.pre_scores.data_ptr(),
+                                 self.pre_counts.data_ptr(), self.kmax, st), "rpn_topk_decode")
+        ck(L.dtc_nms_sorted(self.pre_boxes.data_ptr(), self.pre_counts.data_ptr(), S, self.kmax, self.rpn_thresh, self.P,
+                            self.nms_ws.data_ptr(), self.nms_ws.numel(), self.keep.data_ptr(), self.P,
+                            self.keep_cnt.data_ptr(), st), "nms_sorted")
+        ck(L.dtc_gather_kept(self.pre_boxes.data_ptr(), self.pre_scores.data_ptr(), S, self.kmax, self.keep.data_ptr(),
+                             self.keep_cnt.data_ptr(), self.P, self.prop_boxes.data_ptr(), self.prop_scores.data_ptr(), st),
+           "gather_kept")
+        ck(L.dtc_fpn_collect_distribute(self.prop_boxes.data_ptr(), self.prop_scores.data_ptr(), self.keep_cnt.data_ptr(),
+                                        B, 5, self.P, T, 2, 5, self.rois5.data_ptr(), self.roi_scores.data_ptr(),
+                                        self.roi_levels.data_ptr(), self.n_rois.data_ptr(), self.rois_by_level.data_ptr(),
+                                        self.level_counts.data_ptr(), self.idx_restore.data_ptr(), st), "fpn_collect")
+        self._roi_align_box(st)
+        ck(L.dtc_postprocess_detections(self.rois5.data_ptr(), self.n_rois.data_ptr(), self.cls_score.data_ptr(),
+                                        self.bbox_pred.data_ptr(), self.sf.data_ptr(), self.im_size.data_ptr(), B, T,
+                                        self.n_cls, 10.0, 10.0, 5.0, 5.0, 0.05, 0.5, self.max_det,
+                                        self.det_ws.data_ptr(), self.det_ws.numel(), self.dets.data_ptr(),
+                                        self.det_roi.data_ptr(), self.det_scaled.data_ptr(), self.det_count.data_ptr(), D, st),
+           "postprocess_detections")
+        # mask branch: level ids of the (scaled) detection boxes, multilevel_rois.py:19-39
+        ck(L.dtc_fpn_collect_distribute(self.det_scaled.data_ptr(), None, self.det_count.data_ptr(), B, 1, D, D, 2, 5,
+                                        self.m_rois5.data_ptr(), None, self.m_levels.data_ptr(), self.m_n.data_ptr(),
+                                        self.m_by_level.data_ptr(), self.m_level_counts.data_ptr(),
+                                        self.m_restore.data_ptr(), st), "fpn_map_levels")
+        self._roi_align_mask(st)
+        ck(L.dtc_mask_paste(self.masks.data_ptr(), None, self.n_cls, self.M, self.dets.data_ptr(), self.det_count.data_ptr(),
+                            self.im_size.data_ptr(), B, D, 0.5, 1, self.crops.data_ptr(), self.crop_capacity,
+                            self.mask_boxes.data_ptr(), self.mask_rects.data_ptr(), self.mask_offsets.data_ptr(),
+                            self.mask_bytes.data_ptr(), st), "mask_paste")
+
+    def _roi_align_box(self, st=None):
+        st = st or hip.stream_ptr(self.dev)
+        hip.check(hip.lib().dtc_roi_align_forward(self.feat_lv, 4, self.C, self.feat_code, self.rois5.data_ptr(), 5,
+                                                  self.roi_levels.data_ptr(), self.B * self.top_n, self.box_p, self.box_p,
+                                                  self.sr, self.box_feats.data_ptr(), self.out_code, st), "roi_align(box)")
+
+    def _roi_align_mask(self, st=None):
+        st = st or hip.stream_ptr(self.dev)
+        hip.check(hip.lib().dtc_roi_align_forward(self.feat_lv, 4, self.C, self.feat_code, self.m_rois5.data_ptr(), 5,
+                                                  self.m_levels.data_ptr(), self.B * self.max_out, self.mask_p, self.mask_p,
+                                                  self.sr, self.mask_feats.data_ptr(), self.out_code, st), "roi_align(mask)")
+
+    def step(self, use_graph=True):
+        """One pass over the bound batch on the current stream.  With use_graph the launch sequence is captured once into
+        a hipGraph (after an eager warm-up call) and replayed: the path is ~17 short launches, i.e. launch-bound."""
+        with torch.cuda.device(self.dev):
+            if not use_graph:
+                self._launch()
+                return
+            if self.graph is None:
+                self._launch()                       # eager warm-up (sets function attributes, primes allocations)
+                torch.cuda.synchronize(self.dev)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch()
+                self.graph = g
+            self.graph.replay()
+
+    # ---- algorithmic (compulsory) bytes, SURVEY.md section 8(d) ------------------------------------------------------
+    def box_roialign_bytes(self):
+        fb = sum(f.numel() * f.element_size() for f in self.feats)
+        return fb + self.B * self.top_n * 5 * 4 + self.box_feats.numel() * self.box_feats.element_size()
+
+    def results(self):
+        """Host copy of the detections of the last step: list of dict(boxes, scores, classes) per image."""
+        cnt = self.det_count.cpu().numpy()
+        dets = self.dets.cpu().numpy()
+        out = []
+        for b in range(self.B):
+            n = min(int(cnt[b]), self.max_out)
+            out.append(dict(boxes=dets[b, :n, :4].copy(), scores=dets[b, :n, 4].copy(), classes=dets[b, :n, 5].astype(np.int32)))
+        return out
+
+
+def synthetic_batch(batch, device, seed, channels=256, n_cls=81, top_n=1000, max_out=128, mask_res=28,
+                    feat_dtype=torch.float32, channels_last=False):
+    """COCO-shaped synthetic inputs of SURVEY.md section 8(d), generated on the device (random-init: there are no
+    Detectron weights / COCO images offline).  Returns the argument tuple of FpnRegionPath.bind()."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    shapes = synth.fpn_level_shapes()
+    rn = lambda *s: torch.randn(s, generator=g, device=device)
+    rpn_cls = [torch.sigmoid(rn(batch, 3, h, w) * 2.0 - 2.0) for (h, w) in shapes]
+    rpn_bbox = [rn(batch, 12, h, w) * 0.2 for (h, w) in shapes]
+    feats = [torch.relu(rn(batch, channels, h, w)).to(feat_dtype) for (h, w) in shapes[:4]]
+    if channels_last:
+        feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
+    cls_score = torch.softmax(rn(batch, top_n, n_cls) * 2.0, dim=2).contiguous()
+    bbox_pred = (rn(batch, top_n, 4 * n_cls) * 0.1).contiguous()
+    masks = torch.sigmoid(rn(batch * max_out, n_cls, mask_res, mask_res) * 1.5)
+    sf = torch.full((batch,), 1.6, device=device)
+    im_size = torch.tensor([[500.0, 833.0]] * batch, device=device)
+    return rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, sf, im_size
