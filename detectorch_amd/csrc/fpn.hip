@@ -34,6 +34,8 @@ struct FpnParams {
   float* rois_by_level;      // [B, top_n, 4]   rows grouped by level (the reference's distr_rois, concatenated)
   int32_t* level_counts;     // [B, k_max-k_min+1]
   int32_t* idx_restore;      // [B, top_n]      rois_by_level[idx_restore[r]] == roi r
+  int32_t* roi_order;        // [B, top_n]      (nullable) global row ids b*top_n + r sorted by (level, y centre): the order in
+                             //                 which RoIAlign should VISIT the rois (L2 locality); padding rows last
 };
 
 __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(FpnParams p) {
@@ -130,6 +132,23 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(Fpn
     const float* o = p.rois5 + ((size_t)b * p.top_n + r) * 5;
     reinterpret_cast<float4*>(p.rois_by_level)[(size_t)b * p.top_n + dst] = make_float4(o[1], o[2], o[3], o[4]);
   }
+  if (p.roi_order) {
+    // visiting order for RoIAlign: (level, y centre, rank).  Purely a performance hint; any permutation is correct.
+    __syncthreads();
+    const int np2o = next_pow2(p.top_n);
+    for (int r = tid; r < np2o; r += kFpnThreads) {
+      uint64_t k = kPadKey;
+      if (r < p.top_n) {
+        const int lvl = p.roi_levels[(size_t)b * p.top_n + r];
+        const float* o = p.rois5 + ((size_t)b * p.top_n + r) * 5;
+        const uint32_t yc = (uint32_t)fminf(fmaxf((o[2] + o[4]) * 0.5f, 0.f), 65535.f);
+        k = ((uint64_t)(lvl < 0 ? 15u : (uint32_t)lvl) << 48) | ((uint64_t)yc << 32) | (uint32_t)r;
+      }
+      keys[r] = k;
+    }
+    block_bitonic_sort<kFpnThreads>(keys, np2o);
+    for (int i = tid; i < p.top_n; i += kFpnThreads) p.roi_order[(size_t)b * p.top_n + i] = b * p.top_n + (int)(uint32_t)keys[i];
+  }
 }
 
 }  // namespace dtc
@@ -138,7 +157,7 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
                                        int n_in_levels, int in_stride, int post_nms_top_n, int k_min, int k_max,
                                        float* rois5, float* roi_scores, int32_t* roi_levels, int32_t* n_out,
                                        float* rois_by_level, int32_t* level_counts, int32_t* idx_restore,
-                                       dtc_stream_t stream) {
+                                       int32_t* roi_order, dtc_stream_t stream) {
   if (batch < 0 || n_in_levels < 1 || n_in_levels > dtc::kFpnMaxLevels || in_stride < 1 || post_nms_top_n < 1 ||
       k_max < k_min || k_max - k_min + 1 > dtc::kFpnMaxLevels)
     return DTC_EINVAL;
@@ -151,8 +170,10 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
   p.in_boxes = in_boxes; p.in_scores = in_scores; p.in_counts = in_counts; p.L_in = n_in_levels; p.P = in_stride;
   p.top_n = post_nms_top_n; p.k_min = k_min; p.k_max = k_max; p.rois5 = rois5; p.roi_scores = roi_scores;
   p.roi_levels = roi_levels; p.n_out = n_out; p.rois_by_level = rois_by_level; p.level_counts = level_counts;
-  p.idx_restore = idx_restore;
-  const size_t smem = in_scores ? (size_t)dtc::next_pow2((int)n_max) * sizeof(uint64_t) : 16;
+  p.idx_restore = idx_restore; p.roi_order = roi_order;
+  size_t smem = in_scores ? (size_t)dtc::next_pow2((int)n_max) * sizeof(uint64_t) : 16;
+  if (roi_order) { const size_t so = (size_t)dtc::next_pow2(post_nms_top_n) * sizeof(uint64_t); if (so > smem) smem = so; }
+  if (post_nms_top_n > 16384) return DTC_EUNSUPPORTED;
   if (smem > 64 * 1024) {
     static bool raised = false;
     if (!raised) {

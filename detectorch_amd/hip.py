@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdetectorch_hip.so")
+LIB_PATH = os.environ.get("DETECTORCH_HIP_LIB") or os.path.join(_HERE, "lib", "libdetectorch_hip.so")
 
 DTC_OK = 0
 DTC_F32, DTC_F16 = 0, 1
@@ -51,6 +51,8 @@ def lib():
     L.launch_roi_align_forward_hip.restype = i
     L.dtc_roi_align_forward.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, p, i, i, i, i, p, i, p]
     L.dtc_roi_align_forward.restype = i
+    L.dtc_roi_align_forward_ordered.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, p, p, i, i, i, i, p, i, p]
+    L.dtc_roi_align_forward_ordered.restype = i
     sz = C.c_size_t
     L.dtc_nms_workspace_bytes.argtypes = [i]
     L.dtc_nms_workspace_bytes.restype = sz
@@ -69,7 +71,7 @@ def lib():
     L.dtc_gather_kept.argtypes = [p, p, i, i, p, p, i, p, p, p]
     L.dtc_gather_kept.restype = i
     ll = C.c_longlong
-    L.dtc_fpn_collect_distribute.argtypes = [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p]
+    L.dtc_fpn_collect_distribute.argtypes = [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p]
     L.dtc_fpn_collect_distribute.restype = i
     L.dtc_postprocess_detections_workspace_bytes.argtypes = [i, i, i]
     L.dtc_postprocess_detections_workspace_bytes.restype = sz
@@ -128,7 +130,7 @@ def make_levels(features, spatial_scales):
 
 
 def roi_align_forward(features, spatial_scales, rois, pooled_h, pooled_w, sampling_ratio, roi_levels=None,
-                      out_dtype=None, out=None):
+                      out_dtype=None, out=None, roi_order=None):
     """Multi-level RoIAlign forward (dtc_roi_align_forward).
 
     features: tensor or list of tensors [B,C,H_l,W_l]; rois [R,4|5] float32; roi_levels int32 [R] or None.
@@ -142,16 +144,19 @@ def roi_align_forward(features, spatial_scales, rois, pooled_h, pooled_w, sampli
     rois = rois.contiguous()
     R, cols = (rois.shape[0], rois.shape[1]) if rois.dim() == 2 else (0, 5)
     lv, ch, dt = make_levels(features, spatial_scales)
-    odt = out_dtype or torch.float32
+    odt = out_dtype or (out.dtype if out is not None else torch.float32)
+    if out is not None and (out.dtype != odt or not out.is_contiguous()):
+        raise TypeError("out must be contiguous and of dtype out_dtype")
     if out is None:
         out = torch.empty((R, ch, pooled_h, pooled_w), dtype=odt, device=dev)
     if roi_levels is not None:
         roi_levels = roi_levels.to(torch.int32).contiguous()
     with torch.cuda.device(dev):
-        rc = lib().dtc_roi_align_forward(lv, len(features), ch, _dtype_code(dt), rois.data_ptr(), cols if R else 5,
-                                         roi_levels.data_ptr() if roi_levels is not None else None, R, int(pooled_h),
-                                         int(pooled_w), int(sampling_ratio), out.data_ptr(), _dtype_code(odt),
-                                         stream_ptr(dev))
+        rc = lib().dtc_roi_align_forward_ordered(
+            lv, len(features), ch, _dtype_code(dt), rois.data_ptr(), cols if R else 5,
+            roi_levels.data_ptr() if roi_levels is not None else None,
+            roi_order.to(torch.int32).contiguous().data_ptr() if roi_order is not None else None, R, int(pooled_h),
+            int(pooled_w), int(sampling_ratio), out.data_ptr(), _dtype_code(odt), stream_ptr(dev))
     check(rc, "dtc_roi_align_forward")
     return out
 
@@ -283,7 +288,8 @@ def fpn_collect_distribute(boxes, scores, counts, post_nms_top_n, k_min=2, k_max
                roi_levels=torch.empty((B, T), dtype=i32, device=dev), n_out=torch.empty((B,), dtype=i32, device=dev),
                rois_by_level=torch.empty((B, T, 4), dtype=f32, device=dev),
                level_counts=torch.empty((B, nl), dtype=i32, device=dev),
-               idx_restore=torch.empty((B, T), dtype=i32, device=dev))
+               idx_restore=torch.empty((B, T), dtype=i32, device=dev),
+               roi_order=torch.empty((B, T), dtype=i32, device=dev))
     if scores is not None:
         scores = scores.contiguous()
     counts = counts.to(i32).contiguous()
@@ -292,7 +298,8 @@ def fpn_collect_distribute(boxes, scores, counts, post_nms_top_n, k_min=2, k_max
                                               k_max, out["rois5"].data_ptr(), _ptr(out["roi_scores"]),
                                               out["roi_levels"].data_ptr(), out["n_out"].data_ptr(),
                                               out["rois_by_level"].data_ptr(), out["level_counts"].data_ptr(),
-                                              out["idx_restore"].data_ptr(), stream_ptr(dev))
+                                              out["idx_restore"].data_ptr(), out["roi_order"].data_ptr(),
+                                              stream_ptr(dev))
     check(rc, "dtc_fpn_collect_distribute")
     return out
 

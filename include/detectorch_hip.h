@@ -62,6 +62,15 @@ int dtc_roi_align_forward(const dtc_feat_level* levels, int n_levels, int channe
                           int roi_cols, const int32_t* roi_levels, int n_rois, int pooled_h, int pooled_w,
                           int sampling_ratio, void* out, int out_dtype, dtc_stream_t stream);
 
+/* Same, with an explicit PROCESSING order: workgroup i pools RoI roi_order[i] (int32 [R], a permutation; NULL = identity).
+ * The output row of a RoI does not change.  RoIs arrive in score order (spatially random); visiting them sorted by
+ * (image, level, row) makes concurrently running workgroups read the same band of the feature map, so window re-reads
+ * hit the XCD's L2 instead of HBM.  dtc_fpn_collect_distribute emits such an order. */
+int dtc_roi_align_forward_ordered(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,
+                                  const float* rois, int roi_cols, const int32_t* roi_levels, const int32_t* roi_order,
+                                  int n_rois, int pooled_h, int pooled_w, int sampling_ratio, void* out, int out_dtype,
+                                  dtc_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * A5  Hard NMS
  * --------------------------------------------------------------------------------------------------------------- */
@@ -141,11 +150,13 @@ int dtc_gather_kept(const float* sorted_boxes, const float* sorted_scores, int n
  *   rois5 [B,topN,5] = (b,x1,y1,x2,y2) in collected (score) order; roi_scores [B,topN] (nullable);
  *   roi_levels int32 [B,topN] = level - k_min; n_out int32 [B];
  *   rois_by_level [B,topN,4] + level_counts int32 [B,k_max-k_min+1] = the reference's per-level lists, concatenated;
- *   idx_restore int32 [B,topN] = the reference's rois_idx_restore (:127). */
+ *   idx_restore int32 [B,topN] = the reference's rois_idx_restore (:127);
+ *   roi_order int32 [B,topN] (nullable) = global row ids b*topN + r sorted by (level, y centre): the visiting order for
+ *   dtc_roi_align_forward_ordered (a performance hint, not part of the reference's semantics). */
 int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_scores, const int32_t* in_counts, int batch,
                                int n_in_levels, int in_stride, int post_nms_top_n, int k_min, int k_max, float* rois5,
                                float* roi_scores, int32_t* roi_levels, int32_t* n_out, float* rois_by_level,
-                               int32_t* level_counts, int32_t* idx_restore, dtc_stream_t stream);
+                               int32_t* level_counts, int32_t* idx_restore, int32_t* roi_order, dtc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * A8  Detection post-processing

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--nhwc", action="store_true")
     ap.add_argument("--half", action="store_true")
+    ap.add_argument("--sort", action="store_true", help="visit RoIs sorted by (image, level, y)")
     a = ap.parse_args()
     rs = synth.rng(3, 0)
     shapes = synth.fpn_level_shapes()[:4]
@@ -35,18 +36,23 @@ def main():
         feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
     rois = np.concatenate([np.hstack([np.full((a.rois, 1), b, np.float32), synth.make_rois(rs, a.rois)])
                            for b in range(a.batch)])
-    lv = torch.from_numpy(fpn_level_of(rois[:, 1:])).cuda()
+    lvn = fpn_level_of(rois[:, 1:])
+    order = None
+    if a.sort:
+        yc = (rois[:, 2] + rois[:, 4]) * 0.5
+        order = torch.from_numpy(np.lexsort((yc, lvn, rois[:, 0])).astype(np.int32)).cuda()
+    lv = torch.from_numpy(lvn).cuda()
     print("level histogram:", np.bincount(lv.cpu().numpy(), minlength=4))
     rois = torch.from_numpy(rois).cuda()
     odt = torch.float16 if a.half else torch.float32
     out = torch.empty((rois.shape[0], a.channels, a.pooled, a.pooled), dtype=odt, device="cuda")
     for _ in range(3):
-        hip.roi_align_forward(feats, synth.FPN_ROI_SCALES, rois, a.pooled, a.pooled, 2, roi_levels=lv, out=out)
+        hip.roi_align_forward(feats, synth.FPN_ROI_SCALES, rois, a.pooled, a.pooled, 2, roi_levels=lv, out=out, roi_order=order)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.iters):
-        hip.roi_align_forward(feats, synth.FPN_ROI_SCALES, rois, a.pooled, a.pooled, 2, roi_levels=lv, out=out)
+        hip.roi_align_forward(feats, synth.FPN_ROI_SCALES, rois, a.pooled, a.pooled, 2, roi_levels=lv, out=out, roi_order=order)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
