@@ -279,3 +279,174 @@ DTC_API int dtc_nms(const float* dets, int n, float thresh, void* workspace, siz
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A6  Soft-NMS -- replaces cython_nms.soft_nms (lib/utils_cython/cython_nms.pyx:98-203; entry lib/utils/boxes.py:339-356).
+// Off by default in the reference (do_soft_nms=False, lib/utils/result_utils.py:100) and inherently sequential over the
+// picks, so this is a correctness-first kernel: ONE wavefront walks the reference's in-place array algorithm on an LDS
+// copy -- per pick a wave-wide argmax (first maximum, :128-132), the swap (:135-148), a lane-parallel decay of the rest
+// (:159-187) and, only when some score fell below the threshold, lane 0 replays the reference's swap-with-last loop
+// (:191-199) on the precomputed flags.  Mixed precision exactly as the Cython compiles: `x2 - x1 + 1` etc. are float
+// differences promoted to DOUBLE by the literal 1.0 (see oracle/oracle.c orc_soft_nms).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace dtc {
+
+__global__ __launch_bounds__(64) void soft_nms_kernel(const float* __restrict__ dets_in, int n, float sigma, float Nt,
+                                                      float threshold, int method, float* __restrict__ dets_out,
+                                                      int64_t* __restrict__ inds_out, int32_t* __restrict__ n_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* X1 = reinterpret_cast<float*>(smem);
+  float* Y1 = X1 + n; float* X2 = Y1 + n; float* Y2 = X2 + n; float* S = Y2 + n;
+  int32_t* I = reinterpret_cast<int32_t*>(S + n);
+  unsigned char* dead = reinterpret_cast<unsigned char*>(I + n);
+  const int lane = threadIdx.x;
+  for (int k = lane; k < n; k += 64) {
+    X1[k] = dets_in[k * 5 + 0]; Y1[k] = dets_in[k * 5 + 1]; X2[k] = dets_in[k * 5 + 2]; Y2[k] = dets_in[k * 5 + 3];
+    S[k] = dets_in[k * 5 + 4]; I[k] = k; dead[k] = 0;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
+  int N = n;
+  for (int i = 0; i < N; i++) {
+    // ---- argmax over [i, N): first maximum in scan order (strict <)  :128-132
+    float bs = -INFINITY; int bp = 0x7fffffff;
+    for (int pos = i + lane; pos < N; pos += 64) {
+      const float s = S[pos];
+      if (bp == 0x7fffffff || s > bs) { bs = s; bp = pos; }   // within a lane positions ascend: keep the first max
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float os = __shfl_xor(bs, off, 64);
+      const int op = __shfl_xor(bp, off, 64);
+      const bool take = (op != 0x7fffffff) && (bp == 0x7fffffff || os > bs || (os == bs && op < bp));
+      if (take) { bs = os; bp = op; }
+    }
+    const int maxpos = bp;
+    // ---- swap rows i and maxpos  :135-148
+    if (lane == 0 && maxpos != i) {
+      float t;
+      t = X1[i]; X1[i] = X1[maxpos]; X1[maxpos] = t;
+      t = Y1[i]; Y1[i] = Y1[maxpos]; Y1[maxpos] = t;
+      t = X2[i]; X2[i] = X2[maxpos]; X2[maxpos] = t;
+      t = Y2[i]; Y2[i] = Y2[maxpos]; Y2[maxpos] = t;
+      t = S[i]; S[i] = S[maxpos]; S[maxpos] = t;
+      const int ti = I[i]; I[i] = I[maxpos]; I[maxpos] = ti;
+    }
+    __syncthreads();
+    const float tx1 = X1[i], ty1 = Y1[i], tx2 = X2[i], ty2 = Y2[i];
+    // ---- decay the rest  :159-187
+    bool any_dead = false;
+    for (int pos = i + 1 + lane; pos < N; pos += 64) {
+      const float x1 = X1[pos], y1 = Y1[pos], x2 = X2[pos], y2 = Y2[pos];
+      const float area = (float)(((double)(x2 - x1) + 1.0) * ((double)(y2 - y1) + 1.0));      // :166
+      const float iw = (float)((double)(fminf(tx2, x2) - fmaxf(tx1, x1)) + 1.0);              // :167
+      bool d = false;
+      if (iw > 0.f) {
+        const float ih = (float)((double)(fminf(ty2, y2) - fmaxf(ty1, y1)) + 1.0);            // :169
+        if (ih > 0.f) {
+          const float ua = (float)(((((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0)) + (double)area) -
+                                   (double)(iw * ih));                                       // :171
+          const float ov = fdiv(iw * ih, ua);                                                 // :172
+          float weight;
+          if (method == 1) weight = ov > Nt ? (float)(1.0 - (double)ov) : 1.f;                // :174-178
+          else if (method == 2) weight = (float)exp((double)fdiv(-(ov * ov), sigma));         // :180
+          else weight = ov > Nt ? 0.f : 1.f;                                                  // :182-185
+          const float ns = weight * S[pos];                                                   // :187
+          S[pos] = ns;
+          d = ns < threshold;                                                                 // :191
+        }
+      }
+      dead[pos] = d ? 1 : 0;
+      any_dead |= d;
+    }
+    any_dead = __any(any_dead);
+    __syncthreads();
+    // ---- discard by swap-with-last, replayed sequentially on the flags  :191-199
+    if (any_dead) {
+      if (lane == 0) {
+        int pos = i + 1;
+        while (pos < N) {
+          if (dead[pos]) {
+            X1[pos] = X1[N - 1]; Y1[pos] = Y1[N - 1]; X2[pos] = X2[N - 1]; Y2[pos] = Y2[N - 1]; S[pos] = S[N - 1];
+            I[pos] = I[N - 1]; dead[pos] = dead[N - 1];
+            N = N - 1; pos = pos - 1;
+          }
+          pos = pos + 1;
+        }
+      }
+      N = __shfl(N, 0, 64);
+      __syncthreads();
+    }
+  }
+  for (int k = lane; k < N; k += 64) {
+    dets_out[k * 5 + 0] = X1[k]; dets_out[k * 5 + 1] = Y1[k]; dets_out[k * 5 + 2] = X2[k]; dets_out[k * 5 + 3] = Y2[k];
+    dets_out[k * 5 + 4] = S[k]; inds_out[k] = I[k];
+  }
+  if (lane == 0) *n_out = N;
+}
+
+}  // namespace dtc
+
+// Drop-in for cython_nms.soft_nms(boxes_in, sigma, Nt, threshold, method) (lib/utils_cython/cython_nms.pyx:98): device in /
+// device out.  method 0 hard, 1 linear, 2 gaussian (lib/utils/boxes.py:346).  dets_out [n,5] / inds_out int64 [n] receive
+// the N' surviving rows in selection order, n_out int32 [1] = N'.  n <= 6000.
+DTC_API int dtc_soft_nms(const float* dets, int n, float sigma, float overlap_thresh, float score_thresh, int method,
+                         float* dets_out, int64_t* inds_out, int32_t* n_out, dtc_stream_t stream) {
+  if (n < 0 || !n_out || method < 0 || method > 2) return DTC_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (n == 0) return hipMemsetAsync(n_out, 0, sizeof(int32_t), s) == hipSuccess ? DTC_OK : DTC_ELAUNCH;
+  if (n > 6000) return DTC_EUNSUPPORTED;
+  if (!dets || !dets_out || !inds_out) return DTC_EINVAL;
+  const size_t smem = (size_t)n * (6 * 4 + 1) + 16;
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::soft_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
+    raised = true;
+  }
+  hipLaunchKernelGGL(dtc::soft_nms_kernel, dim3(1), dim3(64), smem, s, dets, n, sigma, overlap_thresh, score_thresh, method,
+                     dets_out, inds_out, n_out);
+  DTC_CHECK_LAUNCH();
+  return DTC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A4 (numpy flavour)  bbox_transform + clip_tiled_boxes for ALL classes -- lib/utils/boxes.py:168-208 and :150-165.
+// The fused detection kernel decodes only the (roi, class) pairs that pass the score threshold; this entry exists for
+// callers of the stand-alone box_utils functions.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace dtc {
+__global__ void bbox_transform_kernel(const float* __restrict__ boxes, const float* __restrict__ deltas, int n, int n_cls,
+                                      float wx, float wy, float ww, float wh, int do_clip, float im_h, float im_w,
+                                      float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * n_cls) return;
+  const int i = t / n_cls;
+  const float* b = boxes + (size_t)i * 4;
+  const float* d = deltas + (size_t)t * 4;
+  const float widths = b[2] - b[0] + 1.0f, heights = b[3] - b[1] + 1.0f;          // boxes.py:178-179
+  const float ctr_x = b[0] + 0.5f * widths, ctr_y = b[1] + 0.5f * heights;        // :180-181
+  const float dx = fdiv(d[0], wx), dy = fdiv(d[1], wy);                           // :184-185
+  float dw = fdiv(d[2], ww), dh = fdiv(d[3], wh);                                 // :186-187
+  dw = fminf(dw, 4.135166556742356f); dh = fminf(dh, 4.135166556742356f);         // :190-191
+  const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;              // :193-194
+  const float pw = fexp_cr(dw) * widths, ph = fexp_cr(dh) * heights;              // :195-196
+  float o0 = pcx - 0.5f * pw, o1 = pcy - 0.5f * ph, o2 = pcx + 0.5f * pw - 1.f, o3 = pcy + 0.5f * ph - 1.f;  // :200-206
+  if (do_clip) {                                                                  // :158-164
+    o0 = fmaxf(fminf(o0, im_w - 1.f), 0.f); o1 = fmaxf(fminf(o1, im_h - 1.f), 0.f);
+    o2 = fmaxf(fminf(o2, im_w - 1.f), 0.f); o3 = fmaxf(fminf(o3, im_h - 1.f), 0.f);
+  }
+  reinterpret_cast<float4*>(out)[t] = make_float4(o0, o1, o2, o3);
+}
+}  // namespace dtc
+
+DTC_API int dtc_bbox_transform(const float* boxes, const float* deltas, int n, int n_cls, float wx, float wy, float ww,
+                               float wh, int do_clip, float im_h, float im_w, float* out, dtc_stream_t stream) {
+  if (n < 0 || n_cls < 1) return DTC_EINVAL;
+  if (n == 0) return DTC_OK;
+  if (!boxes || !deltas || !out) return DTC_EINVAL;
+  const long long total = (long long)n * n_cls;
+  hipLaunchKernelGGL(dtc::bbox_transform_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), boxes, deltas, n, n_cls, wx, wy, ww, wh, do_clip, im_h, im_w, out);
+  DTC_CHECK_LAUNCH();
+  return DTC_OK;
+}

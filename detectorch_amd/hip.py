@@ -79,6 +79,10 @@ def lib():
     L.dtc_postprocess_detections.restype = i
     L.dtc_mask_paste.argtypes = [p, p, i, i, p, p, p, i, i, f, i, p, ll, p, p, p, p, p]
     L.dtc_mask_paste.restype = i
+    L.dtc_soft_nms.argtypes = [p, i, f, f, f, i, p, p, p, p]
+    L.dtc_soft_nms.restype = i
+    L.dtc_bbox_transform.argtypes = [p, p, i, i, f, f, f, f, i, f, f, p, p]
+    L.dtc_bbox_transform.restype = i
     _lib = L
     return L
 
@@ -351,4 +355,34 @@ def mask_paste(masks, dets, det_count, im_size, M, per_image_capacity, mask_inde
                                   out["boxes"].data_ptr(), out["rects"].data_ptr(), out["offsets"].data_ptr(),
                                   out["bytes"].data_ptr(), stream_ptr(dev))
     check(rc, "dtc_mask_paste")
+    return out
+
+
+def soft_nms(dets, sigma, overlap_thresh, score_thresh, method):
+    """dtc_soft_nms: dets [N,5] float32 CUDA -> (dets' [N',5], inds int64 [N'])."""
+    dev = _require_cuda(dets)
+    dets = dets.contiguous()
+    n = dets.shape[0]
+    out = torch.empty((max(n, 1), 5), dtype=torch.float32, device=dev)
+    inds = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().dtc_soft_nms(dets.data_ptr(), n, float(sigma), float(overlap_thresh), float(score_thresh), int(method),
+                                out.data_ptr(), inds.data_ptr(), cnt.data_ptr(), stream_ptr(dev))
+    check(rc, "dtc_soft_nms")
+    k = int(cnt.item())
+    return out[:k], inds[:k]
+
+
+def bbox_transform(boxes, deltas, weights, clip_to=None):
+    """dtc_bbox_transform: boxes [N,4], deltas [N,4K] CUDA float32 -> [N,4K]; clip_to=(im_h, im_w) also clips."""
+    dev = _require_cuda(boxes, deltas)
+    boxes, deltas = boxes.contiguous(), deltas.contiguous()
+    n, k = deltas.shape[0], deltas.shape[1] // 4
+    out = torch.empty_like(deltas)
+    with torch.cuda.device(dev):
+        rc = lib().dtc_bbox_transform(boxes.data_ptr(), deltas.data_ptr(), n, k, *[float(w) for w in weights],
+                                      1 if clip_to is not None else 0, float(clip_to[0]) if clip_to is not None else 0.0,
+                                      float(clip_to[1]) if clip_to is not None else 0.0, out.data_ptr(), stream_ptr(dev))
+    check(rc, "dtc_bbox_transform")
     return out

@@ -31,6 +31,37 @@ def nms(dets, thresh):
     return hip.nms(d, thresh).cpu().numpy()
 
 
+def soft_nms(dets, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, method='linear'):
+    """Apply the soft NMS algorithm (boxes.py:339-356) -> (dets', keep)."""
+    if dets.shape[0] == 0:
+        return dets, []
+    methods = {'hard': 0, 'linear': 1, 'gaussian': 2}
+    assert method in methods, 'Unknown soft_nms method: {}'.format(method)
+    d = torch.from_numpy(np.ascontiguousarray(dets, dtype=np.float32)).to(_dev())
+    out, keep = hip.soft_nms(d, np.float32(sigma), np.float32(overlap_thresh), np.float32(score_thresh), methods[method])
+    return out.cpu().numpy(), keep.cpu().numpy()
+
+
+def bbox_transform(boxes, deltas, weights=(1.0, 1.0, 1.0, 1.0)):
+    """Forward transform boxes + regression deltas -> predicted boxes (boxes.py:168-208)."""
+    if boxes.shape[0] == 0:
+        return np.zeros((0, deltas.shape[1]), dtype=deltas.dtype)
+    dev = _dev()
+    b = torch.from_numpy(np.ascontiguousarray(boxes, dtype=np.float32)).to(dev)
+    d = torch.from_numpy(np.ascontiguousarray(deltas, dtype=np.float32)).to(dev)
+    return hip.bbox_transform(b, d, weights).cpu().numpy()
+
+
+def clip_tiled_boxes(boxes, im_shape):
+    """Clip boxes to image boundaries (boxes.py:150-165); exact min/max, done in place on the host array like the reference."""
+    assert boxes.shape[1] % 4 == 0
+    boxes[:, 0::4] = np.maximum(np.minimum(boxes[:, 0::4], im_shape[1] - 1), 0)
+    boxes[:, 1::4] = np.maximum(np.minimum(boxes[:, 1::4], im_shape[0] - 1), 0)
+    boxes[:, 2::4] = np.maximum(np.minimum(boxes[:, 2::4], im_shape[1] - 1), 0)
+    boxes[:, 3::4] = np.maximum(np.minimum(boxes[:, 3::4], im_shape[0] - 1), 0)
+    return boxes
+
+
 def boxes_area(boxes):
     w = (boxes[:, 2] - boxes[:, 0] + 1)
     h = (boxes[:, 3] - boxes[:, 1] + 1)

@@ -193,6 +193,21 @@ int dtc_mask_paste(const float* masks, const int32_t* mask_index, int n_cls, int
                    int cls_specific_mask, uint8_t* crops, long long per_image_capacity, int32_t* mask_boxes,
                    int32_t* mask_rects, long long* mask_offsets, long long* mask_bytes, dtc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * A6  Soft-NMS  and  A4 (numpy flavour) box decode
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* Drop-in for cython_nms.soft_nms(boxes_in, sigma, Nt, threshold, method)  lib/utils_cython/cython_nms.pyx:98-203 (entry
+ * lib/utils/boxes.py:339-356; method 0 hard / 1 linear / 2 gaussian).  dets float32 [n,5] on the device (not modified);
+ * dets_out [n,5] and inds_out int64 [n] receive the N' surviving rows in SELECTION order, n_out int32 [1] = N'. n <= 6000. */
+int dtc_soft_nms(const float* dets, int n, float sigma, float overlap_thresh, float score_thresh, int method,
+                 float* dets_out, int64_t* inds_out, int32_t* n_out, dtc_stream_t stream);
+
+/* bbox_transform (lib/utils/boxes.py:168-208) optionally followed by clip_tiled_boxes (:150-165): boxes [n,4],
+ * deltas [n,4*n_cls] -> out [n,4*n_cls]. */
+int dtc_bbox_transform(const float* boxes, const float* deltas, int n, int n_cls, float wx, float wy, float ww, float wh,
+                       int do_clip, float im_h, float im_w, float* out, dtc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
