@@ -1,0 +1,353 @@
+"""detector -- same constructor / forward / mask_head call surface as the reference's lib/model/detector.py:129-286, with
+the region-proposal hot path (GenerateProposals, collect/distribute, multi-level RoIAlign) running on the HIP kernels.
+
+What stays plain PyTorch-ROCm (MIOpen / hipBLASLt, "the real dense contractions"): the ResNet-50/101 body, FPN lateral /
+output convs, the RPN head convs, fc6/fc7/cls/bbox linears, the mask-head convs.  torchvision is not required: the
+ResNet is re-declared here with torchvision-compatible parameter names (so the caffe2 blob-name mapping of
+lib/utils/utils.py:44-71 still applies) and the caffe2 stride placement of detector.py:174-179 (stride 2 on the first
+1x1 conv of layer2/3/4).
+
+Differences from the reference:
+  * the FPN path issues ONE batched GenerateProposals call for all 5 levels and ONE multi-level RoIAlign launch whose
+    output is already in collected (score) order -- no per-level Python loop, no torch.cat + index_select
+    (detector.py:251-270);
+  * `channels_last=True` keeps the backbone features NHWC (same logical shape), the layout the RoIAlign kernel reads
+    with full cache lines;
+  * inference only (the reference's README.md:3 scope).
+"""
+import pickle
+from math import log2
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip
+from .collect_and_distribute_fpn_rpn_proposals import CollectAndDistributeFpnRpnProposals
+from .generate_proposals import GenerateProposals
+from .roi_align import RoIAlignFunction, preprocess_rois
+
+
+# ---- ResNet body (torchvision-compatible names) ------------------------------------------------------------------------
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        # caffe2 / Detectron put the stride on the first 1x1 conv (detector.py:174-179)
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=stride, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=1, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+class ResNet(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = self._make(64, layers[0], 1)
+        self.layer2 = self._make(128, layers[1], 2)
+        self.layer3 = self._make(256, layers[2], 2)
+        self.layer4 = self._make(512, layers[3], 2)
+        self.avgpool = nn.AvgPool2d(7, stride=1)
+
+    def _make(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
+                                 nn.BatchNorm2d(planes * 4))
+        mods = [Bottleneck(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * 4
+        mods += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+
+_ARCH = {'resnet50': [3, 4, 6, 3], 'resnet101': [3, 4, 23, 3], 'resnet152': [3, 8, 36, 3]}
+
+
+# ---- heads (detector.py:12-127) ---------------------------------------------------------------------------------------
+class fpn_body(nn.Module):
+    def __init__(self, conv_body, conv_body_layers, fpn_layers):
+        super().__init__()
+        self.conv_body = conv_body
+        chans = [conv_body[conv_body_layers.index(l)][-1].bn3.num_features for l in fpn_layers]
+        self.fpn_lateral = nn.ModuleList([nn.Conv2d(c, 256, 1) for c in chans])
+        self.fpn_output = nn.ModuleList([nn.Conv2d(256, 256, 3, padding=1) for _ in chans])
+        self.fpn_indices = [conv_body_layers.index(l) for l in fpn_layers]
+        self.fpn_layers = fpn_layers
+
+    def forward(self, x):
+        lateral = []
+        for i in range(len(self.conv_body)):
+            x = self.conv_body[i](x)
+            if i in self.fpn_indices:
+                lateral.append(x)
+        lateral = [self.fpn_lateral[i](lateral[i]) for i in range(len(lateral))]
+        for i in range(len(lateral) - 2, -1, -1):                         # top-down, nearest x2 (detector.py:45-46)
+            lateral[i] = F.interpolate(lateral[i + 1], scale_factor=2, mode='nearest') + lateral[i]
+        return [self.fpn_output[i](lateral[i]) for i in range(len(lateral))]
+
+
+class two_layer_mlp_head(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.relu = nn.ReLU(inplace=True)
+        self.fc6 = nn.Linear(256 * 7 * 7, 1024)
+        self.fc7 = nn.Linear(1024, 1024)
+
+    def forward(self, x):
+        x = x.reshape(x.size(0), -1)
+        return self.relu(self.fc7(self.relu(self.fc6(x))))
+
+
+class four_layer_conv(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.relu = nn.ReLU(inplace=True)
+        self.fcn1 = nn.Conv2d(256, 256, 3, padding=1)
+        self.fcn2 = nn.Conv2d(256, 256, 3, padding=1)
+        self.fcn3 = nn.Conv2d(256, 256, 3, padding=1)
+        self.fcn4 = nn.Conv2d(256, 256, 3, padding=1)
+
+    def forward(self, x):
+        for m in (self.fcn1, self.fcn2, self.fcn3, self.fcn4):
+            x = self.relu(m(x))
+        return x
+
+
+class mask_head(nn.Module):
+    def __init__(self, conv_head, roi_spatial_scale, roi_sampling_ratio, output_prob):
+        super().__init__()
+        self.output_prob = output_prob
+        self.conv_head = conv_head
+        self.transposed_conv = nn.ConvTranspose2d(256 if isinstance(conv_head, four_layer_conv) else 2048, 256, 2, stride=2)
+        self.classif_logits = nn.Conv2d(256, 81, 1)
+        self.relu = nn.ReLU(inplace=True)
+        self.use_fpn = isinstance(roi_spatial_scale, list)
+        self.roi_spatial_scale = roi_spatial_scale
+        self.roi_sampling_ratio = roi_sampling_ratio
+        self.roi_height = 14
+        self.roi_width = 14
+
+    def forward(self, x, rois, roi_original_idx=None):
+        # detector.py:99-112
+        if not self.use_fpn:
+            x = RoIAlignFunction.apply(x, preprocess_rois(rois), self.roi_height, self.roi_width,
+                                       self.roi_spatial_scale, self.roi_sampling_ratio)
+        else:
+            # one multi-level launch over the per-level lists; output rows follow the concatenation order, then the
+            # caller's restore permutation is applied exactly like :105-106
+            lv, rs = [], []
+            for i, r in enumerate(rois):
+                if r is None or r.shape[0] == 0:
+                    continue
+                r = preprocess_rois(r)
+                rs.append(r)
+                lv.append(torch.full((r.shape[0],), i, dtype=torch.int32, device=r.device))
+            x = hip.roi_align_forward(list(x)[:len(self.roi_spatial_scale)], self.roi_spatial_scale, torch.cat(rs, 0),
+                                      self.roi_height, self.roi_width, self.roi_sampling_ratio, roi_levels=torch.cat(lv, 0))
+            x = x[roi_original_idx, :]
+        x = self.conv_head(x)
+        x = self.relu(self.transposed_conv(x))
+        x = self.classif_logits(x)
+        return torch.sigmoid(x) if self.output_prob else x
+
+
+class rpn_head(nn.Module):
+    def __init__(self, in_channels=1024, out_channels=1024, n_anchors=15):
+        super().__init__()
+        self.conv_rpn = nn.Conv2d(in_channels, out_channels, 3, padding=1)
+        self.rpn_cls_prob = nn.Conv2d(out_channels, n_anchors, 1)
+        self.rpn_bbox_pred = nn.Conv2d(out_channels, 4 * n_anchors, 1)
+
+    def forward(self, x):
+        c = F.relu(self.conv_rpn(x), inplace=True)
+        return torch.sigmoid(self.rpn_cls_prob(c)), self.rpn_bbox_pred(c)
+
+
+def _caffe2_name(key):
+    """torchvision-style ResNet parameter name -> caffe2 blob name (same mapping as lib/utils/utils.py:44-71)."""
+    t = key.split('.')
+    if t[0] == 'conv1':
+        return 'conv1_w'
+    if t[0] == 'bn1':
+        return 'res_conv1_bn_' + ('s' if t[1] == 'weight' else 'b')
+    stage = 'res%d_%s' % (int(t[0][-1]) + 1, t[1])
+    if t[2] == 'downsample':
+        branch = '_branch1'
+        kind = 'conv' if t[3] == '0' else 'bn'
+    else:
+        branch = '_branch2' + 'abc'[int(t[2][-1]) - 1]
+        kind = 'conv' if t[2].startswith('conv') else 'bn'
+    if kind == 'conv':
+        return stage + branch + '_w'
+    return stage + branch + ('_bn_s' if t[-1] == 'weight' else '_bn_b')
+
+
+class detector(nn.Module):
+    def __init__(self, train=False, arch='resnet50',
+                 conv_body_layers=['conv1', 'bn1', 'relu', 'maxpool', 'layer1', 'layer2', 'layer3'],
+                 conv_head_layers=['layer4', 'avgpool'], fpn_layers=[], fpn_extra_lvl=True, use_rpn_head=False,
+                 use_mask_head=False, mask_head_type='upshare', roi_feature_channels=2048, N_classes=81,
+                 detector_pkl_file=None, base_cnn_pkl_file=None, output_prob=True, roi_height=14, roi_width=14,
+                 roi_spatial_scale=0.0625, roi_sampling_ratio=0, channels_last=False):
+        super().__init__()
+        if train:
+            raise NotImplementedError("detectorch_amd.detector is inference-only")
+        self.roi_height, self.roi_width = int(roi_height), int(roi_width)
+        self.roi_spatial_scale = [float(i) for i in roi_spatial_scale] if isinstance(roi_spatial_scale, list) else float(roi_spatial_scale)
+        self.roi_sampling_ratio = int(roi_sampling_ratio)
+        self.train_mode = train
+        self.mask_head_type = mask_head_type
+        self.use_fpn_body = len(fpn_layers) > 0
+        self.fpn_extra_lvl = fpn_extra_lvl
+        self.use_rpn_head, self.use_mask_head = use_rpn_head, use_mask_head
+        self.use_two_layer_mlp_head = conv_head_layers == 'two_layer_mlp'
+        self.output_prob = output_prob
+        self.channels_last = channels_last
+        if arch not in _ARCH:
+            raise ValueError('Only resnet implemented so far!')
+        self.model = ResNet(_ARCH[arch])
+        self.conv_body = nn.Sequential(*[getattr(self.model, l) for l in conv_body_layers])
+        if self.use_fpn_body:
+            self.conv_body = fpn_body(self.conv_body, conv_body_layers, fpn_layers)
+        if self.use_two_layer_mlp_head:
+            self.conv_head = two_layer_mlp_head()
+            roi_feature_channels = 1024
+        else:
+            self.conv_head = nn.Sequential(*[getattr(self.model, l) for l in conv_head_layers])
+        if self.use_rpn_head and not self.use_fpn_body:
+            self.rpn = rpn_head()
+            self.proposal_generator = GenerateProposals(train=False)
+        if self.use_rpn_head and self.use_fpn_body:
+            self.rpn = rpn_head(in_channels=256, out_channels=256, n_anchors=3)
+            scales = list(self.roi_spatial_scale)
+            if self.fpn_extra_lvl:
+                scales = scales + [scales[-1] / 2.]
+            self.rpn_scales = scales
+            self.proposal_generator = nn.ModuleList([GenerateProposals(train=False, spatial_scale=scales[i],
+                                                                       anchor_sizes=(32 * 2 ** i,), rpn_pre_nms_top_n=1000,
+                                                                       rpn_post_nms_top_n=1000) for i in range(len(scales))])
+            self.collect_and_distr_rois = CollectAndDistributeFpnRpnProposals(spatial_scales=self.roi_spatial_scale)
+        self.bbox_head = nn.Linear(roi_feature_channels, 4 * N_classes)
+        self.classif_head = nn.Linear(roi_feature_channels, N_classes)
+        if self.use_mask_head:
+            mh_conv = self.conv_head[0] if mask_head_type == 'upshare' else four_layer_conv()
+            self.mask_head = mask_head(mh_conv, self.roi_spatial_scale, self.roi_sampling_ratio, output_prob)
+        if detector_pkl_file is not None:
+            self.load_pretrained_weights(detector_pkl_file, model='detector')
+        elif base_cnn_pkl_file is not None:
+            self.load_pretrained_weights(base_cnn_pkl_file, model='base_cnn')
+        self.eval()   # BN layers are caffe2 AffineChannel ops: always eval (detector.py:231)
+
+    # ---- forward (detector.py:233-286) -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, image, rois=None, scaling_factor=None, roi_original_idx=None):
+        h, w = image.size(2), image.size(3)
+        if self.channels_last:
+            image = image.contiguous(memory_format=torch.channels_last)
+        img_features = self.conv_body(image)
+        if self.use_rpn_head and not self.use_fpn_body:
+            rpn_cls_prob, rpn_bbox_pred = self.rpn(img_features)
+            rois, _ = self.proposal_generator(rpn_cls_prob, rpn_bbox_pred, h, w, scaling_factor)
+        fused = None
+        if self.use_rpn_head and self.use_fpn_body:
+            feats = list(img_features)
+            if self.fpn_extra_lvl:
+                feats = feats + [F.max_pool2d(feats[-1], 1, stride=2)]                 # detector.py:250
+            cls_bbox = [self.rpn(f) for f in feats]
+            gens = self.proposal_generator
+            boxes, scores, counts, _, _, _ = hip.generate_proposals(                     # all levels, one call
+                [c for c, _ in cls_bbox], [b for _, b in cls_bbox], [g._anchors for g in gens],
+                [1. / s for s in self.rpn_scales], h, w, [g.rpn_pre_nms_top_n for g in gens],
+                gens[0].rpn_post_nms_top_n, gens[0].rpn_nms_thresh)
+            lv = [int(log2(1 / s)) for s in self.roi_spatial_scale]
+            fused = hip.fpn_collect_distribute(boxes, scores, counts, 1000, lv[0], lv[-1])   # collect...py:86
+        if not self.use_fpn_body:
+            roi_features = RoIAlignFunction.apply(img_features, preprocess_rois(rois), self.roi_height, self.roi_width,
+                                                  self.roi_spatial_scale, self.roi_sampling_ratio)
+        elif fused is not None:
+            n = int(fused["n_out"][0].item())
+            rois5 = fused["rois5"][0, :n]
+            roi_features = hip.roi_align_forward(list(img_features), self.roi_spatial_scale, rois5, self.roi_height,
+                                                 self.roi_width, self.roi_sampling_ratio,
+                                                 roi_levels=fused["roi_levels"][0, :n])
+            rois = rois5[:, 1:]                                   # already in the "restored" order of :269-270
+        else:
+            # FPN with precomputed per-level rois (eval_fast_FPN flow): per-level lists + restore index from the caller
+            lvs = [torch.full((r.shape[0],), i, dtype=torch.int32, device=r.device) for i, r in enumerate(rois)]
+            cat = torch.cat([preprocess_rois(r) for r in rois], 0)
+            roi_features = hip.roi_align_forward(list(img_features), self.roi_spatial_scale, cat, self.roi_height,
+                                                 self.roi_width, self.roi_sampling_ratio, roi_levels=torch.cat(lvs, 0))
+            roi_features = roi_features[roi_original_idx, :]
+            rois = cat[roi_original_idx, 1:]
+        roi_features = self.conv_head(roi_features)
+        roi_features = roi_features.reshape(roi_features.size(0), -1)
+        cls_score = self.classif_head(roi_features)
+        if self.output_prob:
+            cls_score = F.softmax(cls_score, dim=1)
+        bbox_pred = self.bbox_head(roi_features)
+        return cls_score, bbox_pred, rois, img_features
+
+    # ---- caffe2 / Detectron pickle import (detector.py:289-374) -------------------------------------------------------
+    def load_pretrained_weights(self, caffe_pkl_file, model='detector'):
+        with open(caffe_pkl_file, 'rb') as f:
+            blobs = pickle.load(f, encoding='latin1')
+        if model == 'detector':
+            blobs = blobs['blobs']
+        T = lambda name: torch.as_tensor(np.asarray(blobs[name]), dtype=torch.float32)
+        sd = self.model.state_dict()
+        for k in list(sd.keys()):
+            if 'running' in k or 'num_batches' in k or 'fc' in k:
+                continue
+            v = T(_caffe2_name(k))
+            assert sd[k].size() == v.size(), k
+            sd[k] = v[:, (2, 1, 0), :, :] if k == 'conv1.weight' else v        # BGR -> RGB
+        self.model.load_state_dict(sd)
+        if model != 'detector':
+            return
+
+        def put(mod, wname, bname):
+            mod.weight.data = T(wname)
+            mod.bias.data = T(bname)
+        put(self.bbox_head, 'bbox_pred_w', 'bbox_pred_b')
+        put(self.classif_head, 'cls_score_w', 'cls_score_b')
+        if self.use_rpn_head:
+            sfx = '_fpn2' if self.use_fpn_body else ''
+            put(self.rpn.conv_rpn, 'conv_rpn%s_w' % sfx, 'conv_rpn%s_b' % sfx)
+            put(self.rpn.rpn_cls_prob, 'rpn_cls_logits%s_w' % sfx, 'rpn_cls_logits%s_b' % sfx)
+            put(self.rpn.rpn_bbox_pred, 'rpn_bbox_pred%s_w' % sfx, 'rpn_bbox_pred%s_b' % sfx)
+        if self.use_mask_head:
+            put(self.mask_head.transposed_conv, 'conv5_mask_w', 'conv5_mask_b')
+            put(self.mask_head.classif_logits, 'mask_fcn_logits_w', 'mask_fcn_logits_b')
+            if self.mask_head_type == '1up4convs':
+                for i in range(1, 5):
+                    put(getattr(self.mask_head.conv_head, 'fcn%d' % i), '_[mask]_fcn%d_w' % i, '_[mask]_fcn%d_b' % i)
+        if self.use_fpn_body:
+            nl = len(self.conv_body.fpn_layers)
+            for i, l in enumerate(self.conv_body.fpn_layers):
+                last = list(getattr(self.model, l).state_dict().keys())[-1]
+                stem = _caffe2_name(l + '.' + last)
+                stem = stem[:stem.rfind('_branch')]                    # e.g. res2_2
+                suffix = '_sum_lateral' if i < nl - 1 else '_sum'
+                put(self.conv_body.fpn_lateral[i], 'fpn_inner_%s%s_w' % (stem, suffix), 'fpn_inner_%s%s_b' % (stem, suffix))
+                put(self.conv_body.fpn_output[i], 'fpn_%s_sum_w' % stem, 'fpn_%s_sum_b' % stem)
+        if self.use_two_layer_mlp_head:
+            put(self.conv_head.fc6, 'fc6_w', 'fc6_b')
+            put(self.conv_head.fc7, 'fc7_w', 'fc7_b')
