@@ -133,6 +133,15 @@ def main():
     alg_bytes = path.box_roialign_bytes()
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
+    traffic = None
+    try:   # HBM bytes per launch of the same kernel/config from the committed rocprofv3 --pmc passes (profiles/README.md)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "roialign_traffic.json")))
+        key = "b%d_%s_%s" % (a.batch, "nhwc" if a.channels_last else "nchw", "f16" if a.fp16 else "f32")
+        if key in tj:
+            traffic = tj[key]
+    except Exception:
+        traffic = None
+
     if rank == 0:
         n_img = a.batch * a.steps * world
         out = {
@@ -149,7 +158,7 @@ def main():
                        "not_in_path": "ResNet-50/FPN convs and box/mask-head GEMMs (MIOpen/hipBLASLt), outputs synthetic"},
             "roofline": {"bound": "hbm", "kernel": "roi_align_fwd (box head, 4 levels, %d rois)" % (a.batch * 1000),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k_ms, 4)},
         }
         if not a.no_cpu_baseline and world == 1:

@@ -145,6 +145,7 @@ class mask_head(nn.Module):
         self.roi_height = 14
         self.roi_width = 14
 
+    @torch.no_grad()
     def forward(self, x, rois, roi_original_idx=None):
         # detector.py:99-112
         if not self.use_fpn:
