@@ -36,6 +36,7 @@ struct FpnParams {
   int32_t* idx_restore;      // [B, top_n]      rois_by_level[idx_restore[r]] == roi r
   int32_t* roi_order;        // [B, top_n]      (nullable) global row ids b*top_n + r sorted by (level, y centre): the order in
                              //                 which RoIAlign should VISIT the rois (L2 locality); padding rows last
+  float* roi_desc;           // [B, top_n, 8]   (nullable, needs roi_order) packed (b,x1,y1,x2,y2,level,global_row,0) in visiting order
 };
 
 __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(FpnParams p) {
@@ -147,7 +148,16 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(Fpn
       keys[r] = k;
     }
     block_bitonic_sort<kFpnThreads>(keys, np2o);
-    for (int i = tid; i < p.top_n; i += kFpnThreads) p.roi_order[(size_t)b * p.top_n + i] = b * p.top_n + (int)(uint32_t)keys[i];
+    for (int i = tid; i < p.top_n; i += kFpnThreads) {
+      const int r = (int)(uint32_t)keys[i];
+      p.roi_order[(size_t)b * p.top_n + i] = b * p.top_n + r;
+      if (p.roi_desc) {
+        const float* o = p.rois5 + ((size_t)b * p.top_n + r) * 5;
+        float4* d = reinterpret_cast<float4*>(p.roi_desc + ((size_t)b * p.top_n + i) * 8);
+        d[0] = make_float4(o[0], o[1], o[2], o[3]);
+        d[1] = make_float4(o[4], (float)p.roi_levels[(size_t)b * p.top_n + r], (float)(b * p.top_n + r), 0.f);
+      }
+    }
   }
 }
 
@@ -157,7 +167,7 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
                                        int n_in_levels, int in_stride, int post_nms_top_n, int k_min, int k_max,
                                        float* rois5, float* roi_scores, int32_t* roi_levels, int32_t* n_out,
                                        float* rois_by_level, int32_t* level_counts, int32_t* idx_restore,
-                                       int32_t* roi_order, dtc_stream_t stream) {
+                                       int32_t* roi_order, float* roi_desc, dtc_stream_t stream) {
   if (batch < 0 || n_in_levels < 1 || n_in_levels > dtc::kFpnMaxLevels || in_stride < 1 || post_nms_top_n < 1 ||
       k_max < k_min || k_max - k_min + 1 > dtc::kFpnMaxLevels)
     return DTC_EINVAL;
@@ -170,7 +180,7 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
   p.in_boxes = in_boxes; p.in_scores = in_scores; p.in_counts = in_counts; p.L_in = n_in_levels; p.P = in_stride;
   p.top_n = post_nms_top_n; p.k_min = k_min; p.k_max = k_max; p.rois5 = rois5; p.roi_scores = roi_scores;
   p.roi_levels = roi_levels; p.n_out = n_out; p.rois_by_level = rois_by_level; p.level_counts = level_counts;
-  p.idx_restore = idx_restore; p.roi_order = roi_order;
+  p.idx_restore = idx_restore; p.roi_order = roi_order; p.roi_desc = roi_order ? roi_desc : nullptr;
   size_t smem = in_scores ? (size_t)dtc::next_pow2((int)n_max) * sizeof(uint64_t) : 16;
   if (roi_order) { const size_t so = (size_t)dtc::next_pow2(post_nms_top_n) * sizeof(uint64_t); if (so > smem) smem = so; }
   if (post_nms_top_n > 16384) return DTC_EUNSUPPORTED;

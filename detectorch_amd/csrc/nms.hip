@@ -11,6 +11,9 @@
 //                            into a register-resident `removed` bit-vector (lane l owns words l, l+64, ...).
 // Output order: positions in score order (what `keep[:post_nms_top_n]` needs, generate_proposals.py:117); dtc_nms()
 // additionally maps back to ascending original indices like np.where(suppressed == 0)[0]  [:87].
+#include <stdlib.h>
+#include <string.h>
+
 #include "block_sort.h"
 #include "dtc_common.h"
 
@@ -55,38 +58,60 @@ __global__ __launch_bounds__(kSortThreads) void segment_sort_desc_kernel(
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float box_area(float4 b) { return (b.z - b.x + 1.f) * (b.w - b.y + 1.f); }  // cython_nms.pyx:44
 
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ boxes,
-                                                      const int32_t* __restrict__ counts, int n_stride, int ncb_stride,
-                                                      float thresh, uint64_t* __restrict__ mask) {
-  const int cb = blockIdx.x, rb = blockIdx.y, s = blockIdx.z;
-  if (cb < rb) return;
+constexpr int kMaskWaves = 4;  // a workgroup = 4 wavefronts = 4 consecutive column blocks of one row block
+
+__global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4* __restrict__ boxes,
+                                                                   const int32_t* __restrict__ counts, int n_stride,
+                                                                   int ncb_stride, float thresh, double mid,
+                                                                   int cmp_mode, uint64_t* __restrict__ mask) {
+  __shared__ float4 rbox_s[64];
+  __shared__ float rarea_s[64];
+  const int rb = blockIdx.y, s = blockIdx.z;
+  const int cb0 = blockIdx.x * kMaskWaves;
+  if (cb0 + kMaskWaves - 1 < rb) return;                      // whole workgroup below the diagonal
   const int n = counts ? min(counts[s], n_stride) : n_stride;
-  if (cb * 64 >= n) return;
-  const int lane = threadIdx.x;
+  if (rb * 64 >= n) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float4* B = boxes + (size_t)s * n_stride;
-  const int col = cb * 64 + lane, row = rb * 64 + lane;
-  const float4 cbox = col < n ? B[col] : make_float4(0.f, 0.f, -1.f, -1.f);
-  const float4 rbox = row < n ? B[row] : make_float4(0.f, 0.f, -1.f, -1.f);
-  const float carea = box_area(cbox), rarea = box_area(rbox);
+  if (wv == 0) {
+    const int row = rb * 64 + lane;
+    const float4 rbx = row < n ? B[row] : make_float4(0.f, 0.f, -1.f, -1.f);
+    rbox_s[lane] = rbx;
+    rarea_s[lane] = box_area(rbx);
+  }
+  __syncthreads();
+  const int cb = cb0 + wv;
+  if (cb < rb || cb * 64 >= n) return;
+  const int col = cb * 64 + lane;
   const bool col_ok = col < n;
+  const float4 cbox = col_ok ? B[col] : make_float4(0.f, 0.f, -1.f, -1.f);
+  const float carea = box_area(cbox);
   uint64_t myword = 0;
-#pragma unroll
+#pragma unroll 8
   for (int i = 0; i < 64; i++) {
-    // row box i of this row block, broadcast through SGPRs
-    const float ix1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbox.x), i));
-    const float iy1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbox.y), i));
-    const float ix2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbox.z), i));
-    const float iy2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbox.w), i));
-    const float iarea = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rarea), i));
-    const float xx1 = fmaxf(ix1, cbox.x), yy1 = fmaxf(iy1, cbox.y);          // :76-77
-    const float xx2 = fminf(ix2, cbox.z), yy2 = fminf(iy2, cbox.w);          // :78-79
+    const float4 r = rbox_s[i];                                // uniform address: LDS broadcast
+    const float iarea = rarea_s[i];
+    const float xx1 = fmaxf(r.x, cbox.x), yy1 = fmaxf(r.y, cbox.y);          // cython_nms.pyx:76-77
+    const float xx2 = fminf(r.z, cbox.z), yy2 = fminf(r.w, cbox.w);          // :78-79
     const float w = fmaxf(0.0f, xx2 - xx1 + 1.f), h = fmaxf(0.0f, yy2 - yy1 + 1.f);  // :80-81
     const float inter = w * h;                                               // :82
-    const float ovr = fdiv(inter, iarea + carea - inter);                    // :83
-    const bool sup = col_ok && (col > rb * 64 + i) && (ovr >= thresh);       // :72 (_j > _i), :84
+    // :83-84  `inter / (iarea + areas[j] - inter) >= thresh` with an IEEE float division.  Division-free and EXACT: the
+    // rounded quotient is >= thresh iff the real quotient is >= mid = (pred(thresh) + thresh)/2 (ties-to-even decides the
+    // equality case: cmp_mode 1 -> '>=', 2 -> '>'), i.e. inter >= mid * u; mid has 25 significant bits and u 24, so the
+    // double product is exact.  u <= 0 (degenerate boxes) or cmp_mode 0 (odd thresholds) take the division.
+    const float u = iarea + carea - inter;
+    bool ge;
+    if (cmp_mode != 0 && u > 0.f) {
+      const double lhs = (double)inter, rhs = mid * (double)u;
+      ge = cmp_mode == 1 ? (lhs >= rhs) : (lhs > rhs);
+    } else {
+      ge = fdiv(inter, u) >= thresh;
+    }
+    const bool sup = col_ok && (col > rb * 64 + i) && ge;                    // :72 (_j > _i), :84
     const uint64_t word = __ballot(sup);
     if (lane == i) myword = word;
   }
+  const int row = rb * 64 + lane;
   if (row < n) mask[((size_t)s * n_stride + row) * ncb_stride + cb] = myword;
 }
 
@@ -100,68 +125,77 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-template <int WPL>
+// One wavefront per segment.  lane = (rg, cbl): row group rg = lane >> 4 owns rows r = 4k + rg of the current 64-row
+// block, cbl = lane & 15 one column word of a 16-word chunk.  All 16 loads of a (row block, chunk) are independent of the
+// resolve and are issued together (the diagonal chunk and diag words of the NEXT row block are prefetched while the current
+// one is resolved), so a row block costs one overlapped L2 round trip instead of two dependent ones.
+struct ReduceRegs { uint64_t w[16]; uint64_t diag; };
+
+__device__ __forceinline__ void reduce_load(ReduceRegs& R, const uint64_t* __restrict__ M, int ncb_stride, int n, int ncb,
+                                            int rb, int cbase, bool with_diag) {
+  const int lane = threadIdx.x, rg = lane >> 4, cbl = lane & 15;
+  const int c = cbase + cbl;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int row = rb * 64 + 4 * k + rg;
+    R.w[k] = (row < n && c < ncb && c > rb) ? M[(size_t)row * ncb_stride + c] : 0ull;
+  }
+  if (with_diag) {
+    const int row = rb * 64 + lane;
+    R.diag = row < n ? M[(size_t)row * ncb_stride + rb] : 0ull;
+  }
+}
+
 __global__ __launch_bounds__(64) void nms_reduce_kernel(const uint64_t* __restrict__ mask,
                                                         const int32_t* __restrict__ counts, int n_stride,
                                                         int ncb_stride, int max_keep, int32_t* __restrict__ keep,
                                                         int keep_stride, int32_t* __restrict__ keep_count) {
-  const int s = blockIdx.x, lane = threadIdx.x;
+  __shared__ uint64_t removed[256];            // one bit per box, up to 16384 boxes
+  const int s = blockIdx.x, lane = threadIdx.x, rg = lane >> 4, cbl = lane & 15;
   const int n = counts ? min(counts[s], n_stride) : n_stride;
   const int ncb = (n + 63) >> 6;
   const uint64_t* M = mask + (size_t)s * n_stride * ncb_stride;
   int32_t* K = keep + (size_t)s * keep_stride;
   const int cap = max_keep > 0 ? min(max_keep, keep_stride) : keep_stride;
-  uint64_t removed[WPL];
-#pragma unroll
-  for (int k = 0; k < WPL; k++) removed[k] = 0;
+  for (int i = lane; i < 256; i += 64) removed[i] = 0;
+  __syncthreads();
   int kept = 0;
+  ReduceRegs cur, nxt;
+  if (ncb > 0) reduce_load(cur, M, ncb_stride, n, ncb, 0, 0, true);
   for (int rb = 0; rb < ncb && kept < cap; rb++) {
-    const int row = rb * 64 + lane;
-    const uint64_t diag = row < n ? M[(size_t)row * ncb_stride + rb] : 0;
-    // `removed` word of this row block lives in lane (rb & 63), slot (rb >> 6)
-    uint64_t rem = 0;
-#pragma unroll
-    for (int k = 0; k < WPL; k++)
-      if ((rb >> 6) == k) rem = readlane64(removed[k], rb & 63);
+    const int cbase0 = rb & ~15;
+    if (rb + 1 < ncb) reduce_load(nxt, M, ncb_stride, n, ncb, rb + 1, (rb + 1) & ~15, true);   // prefetch
     const int left = n - rb * 64;
     const uint64_t valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
-    uint64_t cand = valid & ~rem;
+    uint64_t cand = valid & ~removed[rb];
+    cand = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cand >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cand);   // uniform by construction: keep it in SGPRs
     uint64_t keepw = 0;
-    while (cand != 0 && kept < cap) {  // scalar loop over KEPT rows only
+    while (cand != 0 && kept < cap) {          // scalar loop over KEPT rows only
       const int i = __builtin_ctzll(cand);
       keepw |= 1ull << i;
       kept++;
-      cand &= ~(readlane64(diag, i) | (1ull << i));
+      cand &= ~(readlane64(cur.diag, i) | (1ull << i));
     }
-    // emit kept positions in order
     if ((keepw >> lane) & 1ull) {
       const int before = __builtin_popcountll(keepw & ((1ull << lane) - 1ull));
-      K[kept - __builtin_popcountll(keepw) + before] = row;
+      K[kept - __builtin_popcountll(keepw) + before] = rb * 64 + lane;
     }
-    // removed |= OR of the kept rows (column blocks > rb only)
     if (rb + 1 < ncb && kept < cap) {
-      uint64_t kw = keepw;
-      while (kw != 0) {
-        int r[4];
-        int m = 0;
+      for (int cbase = cbase0; cbase < ncb; cbase += 16) {
+        if (cbase != cbase0) reduce_load(cur, M, ncb_stride, n, ncb, rb, cbase, false);
+        uint64_t acc = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          if (kw != 0) { r[q] = __builtin_ctzll(kw); kw &= kw - 1; m = q + 1; } else { r[q] = -1; }
-        }
-        uint64_t v[4][WPL];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-          for (int k = 0; k < WPL; k++) {
-            const int c = k * 64 + lane;
-            v[q][k] = (q < m && c > rb && c < ncb) ? M[(size_t)(rb * 64 + r[q]) * ncb_stride + c] : 0ull;
-          }
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-          for (int k = 0; k < WPL; k++) removed[k] |= v[q][k];
+        for (int k = 0; k < 16; k++)
+          if ((keepw >> (4 * k + rg)) & 1ull) acc |= cur.w[k];
+        uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+        lo |= __shfl_xor(lo, 16, 64); hi |= __shfl_xor(hi, 16, 64);
+        lo |= __shfl_xor(lo, 32, 64); hi |= __shfl_xor(hi, 32, 64);
+        if (rg == 0 && cbase + cbl < ncb) removed[cbase + cbl] |= ((uint64_t)hi << 32) | lo;
       }
+      __syncthreads();
     }
+    cur = nxt;
   }
   if (lane == 0) keep_count[s] = kept;
 }
@@ -206,15 +240,26 @@ DTC_API int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg,
   const int ncb = (n_stride + 63) / 64;
   if (ncb > 64 * 4) return DTC_EUNSUPPORTED;  // > 16384 boxes per segment
   uint64_t* mask = reinterpret_cast<uint64_t*>(workspace);
-  hipLaunchKernelGGL(dtc::nms_mask_kernel, dim3(ncb, ncb, n_seg), dim3(64), 0, s,
-                     reinterpret_cast<const float4*>(boxes), counts, n_stride, ncb, thresh, mask);
+  // exact division-free threshold test (see nms_mask_kernel): only for normal positive thresholds
+  double mid = 0.0;
+  int cmp_mode = 0;
+  // Measured on MI355X: the fp64 convert/multiply/compare sequence is SLOWER than the IEEE float division here
+  // (nms_mask 87 -> 102 us for 40 RPN segments), so the exact division-free test stays disabled (cmp_mode 0).
+  if (getenv("DTC_NMS_NODIV") && thresh > 1e-30f && thresh < 1e30f) {
+    uint32_t tb;
+    memcpy(&tb, &thresh, sizeof(tb));
+    const uint32_t pb = tb - 1;                       // pred(thresh) for a positive normal float
+    float tp;
+    memcpy(&tp, &pb, sizeof(tp));
+    mid = ((double)thresh + (double)tp) * 0.5;
+    cmp_mode = (tb & 1u) == 0 ? 1 : 2;                // tie rounds to the even mantissa
+  }
+  hipLaunchKernelGGL(dtc::nms_mask_kernel, dim3((ncb + dtc::kMaskWaves - 1) / dtc::kMaskWaves, ncb, n_seg),
+                     dim3(64 * dtc::kMaskWaves), 0, s, reinterpret_cast<const float4*>(boxes), counts, n_stride, ncb, thresh,
+                     mid, cmp_mode, mask);
   DTC_CHECK_LAUNCH();
-  if (ncb <= 64)
-    hipLaunchKernelGGL(dtc::nms_reduce_kernel<1>, dim3(n_seg), dim3(64), 0, s, mask, counts, n_stride, ncb, max_keep, keep, keep_stride, keep_count);
-  else if (ncb <= 128)
-    hipLaunchKernelGGL(dtc::nms_reduce_kernel<2>, dim3(n_seg), dim3(64), 0, s, mask, counts, n_stride, ncb, max_keep, keep, keep_stride, keep_count);
-  else
-    hipLaunchKernelGGL(dtc::nms_reduce_kernel<4>, dim3(n_seg), dim3(64), 0, s, mask, counts, n_stride, ncb, max_keep, keep, keep_stride, keep_count);
+  hipLaunchKernelGGL(dtc::nms_reduce_kernel, dim3(n_seg), dim3(64), 0, s, mask, counts, n_stride, ncb, max_keep, keep,
+                     keep_stride, keep_count);
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }

@@ -24,6 +24,8 @@ struct RoiAlignParams {
   const float* rois;
   const int32_t* roi_levels;
   const int32_t* roi_order;   // optional processing order: workgroup i handles RoI roi_order[i] (output row unchanged)
+  const float* roi_desc;      // optional packed descriptors [R,8] in VISITING order: (batch, x1, y1, x2, y2, level, out_row, 0)
+                              // one 32-byte load instead of three dependent global loads at the head of every workgroup
   void* out;
   int n_levels, channels, roi_cols, n_rois, pooled_h, pooled_w, sampling_ratio, ch_tile;
   int ch_block;   // channels per workgroup of the LDS kernel (multiple of 64): setup (tables, window) is paid once per block
@@ -351,22 +353,30 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   const int nct = ceil_div(p.channels, p.ch_block);
   const int ri = blockIdx.x / nct;
   const int c0 = (blockIdx.x - ri * nct) * p.ch_block;
-  const int r = p.roi_order ? p.roi_order[ri] : ri;
   const int nc = min(p.ch_block, p.channels - c0);
   const int bins = p.pooled_h * p.pooled_w;
   const int tid = threadIdx.x;
-  const int lvl = p.roi_levels ? p.roi_levels[r] : 0;
+  int r, lvl, b = 0;
+  float rx1, ry1, rx2, ry2;
+  if (p.roi_desc) {
+    const float4 d0 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2];
+    const float4 d1 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2 + 1];
+    b = (int)d0.x; rx1 = d0.y; ry1 = d0.z; rx2 = d0.w; ry2 = d1.x; lvl = (int)d1.y; r = (int)d1.z;
+  } else {
+    r = p.roi_order ? p.roi_order[ri] : ri;
+    lvl = p.roi_levels ? p.roi_levels[r] : 0;
+    const float* roi = p.rois + (size_t)r * p.roi_cols;
+    if (p.roi_cols == 5) { b = (int)roi[0]; roi++; }
+    rx1 = roi[0]; ry1 = roi[1]; rx2 = roi[2]; ry2 = roi[3];
+  }
   TOut* out = reinterpret_cast<TOut*>(p.out) + ((size_t)r * p.channels + c0) * bins;
   if (lvl < 0 || lvl >= p.n_levels) {  // padding row (fpn.hip emits level -1): defined output
     for (int o = tid; o < nc * bins; o += kRoiAlignThreads) out[o] = from_f32<TOut>(0.f);
     return;
   }
   const dtc_feat_level L = p.lv[lvl];
-  const float* roi = p.rois + (size_t)r * p.roi_cols;
-  int b = 0;
-  if (p.roi_cols == 5) { b = (int)roi[0]; roi++; }
   const float s = L.spatial_scale;
-  const float sw = roi[0] * s, sh = roi[1] * s, ew = roi[2] * s, eh = roi[3] * s;
+  const float sw = rx1 * s, sh = ry1 * s, ew = rx2 * s, eh = ry2 * s;
   const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
   const float bin_h = fdiv(rh, (float)p.pooled_h), bin_w = fdiv(rw, (float)p.pooled_w);
   const int g = p.sampling_ratio;
@@ -472,19 +482,19 @@ static int launch_general(const RoiAlignParams& p, hipStream_t stream) {
 
 }  // namespace dtc
 
-DTC_API int dtc_roi_align_forward_ordered(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,
-                                             const float* rois, int roi_cols, const int32_t* roi_levels,
-                                             const int32_t* roi_order, int n_rois, int pooled_h, int pooled_w,
-                                             int sampling_ratio, void* out, int out_dtype, dtc_stream_t stream) {
+static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype, const float* rois,
+                             int roi_cols, const int32_t* roi_levels, const int32_t* roi_order, const float* roi_desc,
+                             int n_rois, int pooled_h, int pooled_w, int sampling_ratio, void* out, int out_dtype,
+                             dtc_stream_t stream) {
   if (!levels || n_levels < 1 || n_levels > DTC_MAX_LEVELS || channels < 1 || n_rois < 0 || pooled_h < 1 ||
-      pooled_w < 1 || (roi_cols != 4 && roi_cols != 5) || (n_rois > 0 && (!rois || !out)))
+      pooled_w < 1 || (roi_cols != 4 && roi_cols != 5) || (n_rois > 0 && ((!rois && !roi_desc) || !out)))
     return DTC_EINVAL;
   dtc::RoiAlignParams p;
   for (int i = 0; i < n_levels; i++) {
     if (!levels[i].data || levels[i].height < 1 || levels[i].width < 1) return DTC_EINVAL;
     p.lv[i] = levels[i];
   }
-  p.rois = rois; p.roi_levels = roi_levels; p.roi_order = roi_order; p.out = out;
+  p.rois = rois; p.roi_levels = roi_levels; p.roi_order = roi_order; p.roi_desc = roi_desc; p.out = out;
   p.n_levels = n_levels; p.channels = channels; p.roi_cols = roi_cols; p.n_rois = n_rois;
   p.pooled_h = pooled_h; p.pooled_w = pooled_w; p.sampling_ratio = sampling_ratio;
   p.ch_tile = channels < 64 ? channels : 64;
@@ -496,6 +506,7 @@ DTC_API int dtc_roi_align_forward_ordered(const dtc_feat_level* levels, int n_le
   if (getenv("DTC_RA_CHBLOCK")) p.ch_block = atoi(getenv("DTC_RA_CHBLOCK"));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // fixed sampling grid with small tables -> LDS-staged kernel; adaptive sampling (sampling_ratio <= 0) -> general kernel
+  if (roi_desc && !(sampling_ratio > 0)) return DTC_EUNSUPPORTED;   // packed descriptors: LDS kernel only
   const bool lds_ok = sampling_ratio > 0 && (pooled_h + pooled_w) * sampling_ratio * 4 <= dtc::kLdsTableFloats &&
                       (long long)pooled_h * pooled_w * 8 <= 4096 && getenv("DTC_ROIALIGN_GENERAL") == nullptr;
   if (lds_ok) {
@@ -510,6 +521,21 @@ DTC_API int dtc_roi_align_forward_ordered(const dtc_feat_level* levels, int n_le
   if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return dtc::launch_general<__half, __half>(p, s);
   if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return dtc::launch_general<float, __half>(p, s);
   return DTC_EUNSUPPORTED;
+}
+
+DTC_API int dtc_roi_align_forward_ordered(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,
+                                             const float* rois, int roi_cols, const int32_t* roi_levels,
+                                             const int32_t* roi_order, int n_rois, int pooled_h, int pooled_w,
+                                             int sampling_ratio, void* out, int out_dtype, dtc_stream_t stream) {
+  return roi_align_dispatch(levels, n_levels, channels, in_dtype, rois, roi_cols, roi_levels, roi_order, nullptr, n_rois,
+                            pooled_h, pooled_w, sampling_ratio, out, out_dtype, stream);
+}
+
+DTC_API int dtc_roi_align_forward_packed(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,
+                                            const float* roi_desc, int n_rois, int pooled_h, int pooled_w,
+                                            int sampling_ratio, void* out, int out_dtype, dtc_stream_t stream) {
+  return roi_align_dispatch(levels, n_levels, channels, in_dtype, nullptr, 5, nullptr, nullptr, roi_desc, n_rois, pooled_h,
+                            pooled_w, sampling_ratio, out, out_dtype, stream);
 }
 
 DTC_API int dtc_roi_align_forward(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,

@@ -71,7 +71,9 @@ def lib():
     L.dtc_gather_kept.argtypes = [p, p, i, i, p, p, i, p, p, p]
     L.dtc_gather_kept.restype = i
     ll = C.c_longlong
-    L.dtc_fpn_collect_distribute.argtypes = [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p]
+    L.dtc_fpn_collect_distribute.argtypes = [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p, p]
+    L.dtc_roi_align_forward_packed.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, i, i, i, p, i, p]
+    L.dtc_roi_align_forward_packed.restype = i
     L.dtc_fpn_collect_distribute.restype = i
     L.dtc_postprocess_detections_workspace_bytes.argtypes = [i, i, i]
     L.dtc_postprocess_detections_workspace_bytes.restype = sz
@@ -293,7 +295,8 @@ def fpn_collect_distribute(boxes, scores, counts, post_nms_top_n, k_min=2, k_max
                rois_by_level=torch.empty((B, T, 4), dtype=f32, device=dev),
                level_counts=torch.empty((B, nl), dtype=i32, device=dev),
                idx_restore=torch.empty((B, T), dtype=i32, device=dev),
-               roi_order=torch.empty((B, T), dtype=i32, device=dev))
+               roi_order=torch.empty((B, T), dtype=i32, device=dev),
+               roi_desc=torch.empty((B, T, 8), dtype=f32, device=dev))
     if scores is not None:
         scores = scores.contiguous()
     counts = counts.to(i32).contiguous()
@@ -303,7 +306,7 @@ def fpn_collect_distribute(boxes, scores, counts, post_nms_top_n, k_min=2, k_max
                                               out["roi_levels"].data_ptr(), out["n_out"].data_ptr(),
                                               out["rois_by_level"].data_ptr(), out["level_counts"].data_ptr(),
                                               out["idx_restore"].data_ptr(), out["roi_order"].data_ptr(),
-                                              stream_ptr(dev))
+                                              out["roi_desc"].data_ptr(), stream_ptr(dev))
     check(rc, "dtc_fpn_collect_distribute")
     return out
 

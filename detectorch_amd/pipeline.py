@@ -58,7 +58,7 @@ class FpnRegionPath:
         self.rois5, self.roi_scores = e(B, T, 5), e(B, T)
         self.roi_levels, self.n_rois = e(B, T, dtype=i32), e(B, dtype=i32)
         self.rois_by_level, self.level_counts, self.idx_restore = e(B, T, 4), e(B, 4, dtype=i32), e(B, T, dtype=i32)
-        self.roi_order = e(B, T, dtype=i32)
+        self.roi_order, self.roi_desc = e(B, T, dtype=i32), e(B, T, 8)
         self.box_feats = e(B * T, self.C, self.box_p, self.box_p, dtype=self.feat_dtype)
         D = self.max_out
         self.dets, self.det_roi = torch.zeros((B, D, 6), device=dev), torch.zeros((B, D), dtype=i32, device=dev)
@@ -67,7 +67,7 @@ class FpnRegionPath:
         self.det_count_c = e(B, 1, dtype=i32)
         self.m_rois5, self.m_levels, self.m_n = e(B, D, 5), e(B, D, dtype=i32), e(B, dtype=i32)
         self.m_by_level, self.m_level_counts, self.m_restore = e(B, D, 4), e(B, 4, dtype=i32), e(B, D, dtype=i32)
-        self.m_order = e(B, D, dtype=i32)
+        self.m_order, self.m_desc = e(B, D, dtype=i32), e(B, D, 8)
         self.mask_feats = e(B * D, self.C, self.mask_p, self.mask_p, dtype=self.feat_dtype)
         self.crops = torch.empty((B, self.crop_capacity), dtype=torch.uint8, device=dev)
         self.mask_boxes, self.mask_rects = torch.zeros((B, D, 4), dtype=i32, device=dev), torch.zeros((B, D, 4), dtype=i32, device=dev)
@@ -104,7 +104,7 @@ class FpnRegionPath:
                                         B, 5, self.P, T, 2, 5, self.rois5.data_ptr(), self.roi_scores.data_ptr(),
                                         self.roi_levels.data_ptr(), self.n_rois.data_ptr(), self.rois_by_level.data_ptr(),
                                         self.level_counts.data_ptr(), self.idx_restore.data_ptr(),
-                                        self.roi_order.data_ptr(), st), "fpn_collect")
+                                        self.roi_order.data_ptr(), self.roi_desc.data_ptr(), st), "fpn_collect")
         self._roi_align_box(st)
         ck(L.dtc_postprocess_detections(self.rois5.data_ptr(), self.n_rois.data_ptr(), self.cls_score.data_ptr(),
                                         self.bbox_pred.data_ptr(), self.sf.data_ptr(), self.im_size.data_ptr(), B, T,
@@ -116,7 +116,8 @@ class FpnRegionPath:
         ck(L.dtc_fpn_collect_distribute(self.det_scaled.data_ptr(), None, self.det_count.data_ptr(), B, 1, D, D, 2, 5,
                                         self.m_rois5.data_ptr(), None, self.m_levels.data_ptr(), self.m_n.data_ptr(),
                                         self.m_by_level.data_ptr(), self.m_level_counts.data_ptr(),
-                                        self.m_restore.data_ptr(), self.m_order.data_ptr(), st), "fpn_map_levels")
+                                        self.m_restore.data_ptr(), self.m_order.data_ptr(), self.m_desc.data_ptr(), st),
+           "fpn_map_levels")
         self._roi_align_mask(st)
         ck(L.dtc_mask_paste(self.masks.data_ptr(), None, self.n_cls, self.M, self.dets.data_ptr(), self.det_count.data_ptr(),
                             self.im_size.data_ptr(), B, D, 0.5, 1, self.crops.data_ptr(), self.crop_capacity,
@@ -125,14 +126,14 @@ class FpnRegionPath:
 
     def _roi_align_box(self, st=None):
         st = st or hip.stream_ptr(self.dev)
-        hip.check(hip.lib().dtc_roi_align_forward_ordered(self.feat_lv, 4, self.C, self.feat_code, self.rois5.data_ptr(), 5,
-                                                  self.roi_levels.data_ptr(), self.roi_order.data_ptr(), self.B * self.top_n, self.box_p, self.box_p,
+        hip.check(hip.lib().dtc_roi_align_forward_packed(self.feat_lv, 4, self.C, self.feat_code, self.roi_desc.data_ptr(),
+                                                  self.B * self.top_n, self.box_p, self.box_p,
                                                   self.sr, self.box_feats.data_ptr(), self.out_code, st), "roi_align(box)")
 
     def _roi_align_mask(self, st=None):
         st = st or hip.stream_ptr(self.dev)
-        hip.check(hip.lib().dtc_roi_align_forward_ordered(self.feat_lv, 4, self.C, self.feat_code, self.m_rois5.data_ptr(), 5,
-                                                  self.m_levels.data_ptr(), self.m_order.data_ptr(), self.B * self.max_out, self.mask_p, self.mask_p,
+        hip.check(hip.lib().dtc_roi_align_forward_packed(self.feat_lv, 4, self.C, self.feat_code, self.m_desc.data_ptr(),
+                                                  self.B * self.max_out, self.mask_p, self.mask_p,
                                                   self.sr, self.mask_feats.data_ptr(), self.out_code, st), "roi_align(mask)")
 
     def step(self, use_graph=True):

@@ -71,6 +71,13 @@ int dtc_roi_align_forward_ordered(const dtc_feat_level* levels, int n_levels, in
                                   int n_rois, int pooled_h, int pooled_w, int sampling_ratio, void* out, int out_dtype,
                                   dtc_stream_t stream);
 
+/* Same, driven by packed descriptors: roi_desc float32 [R,8] = (batch, x1, y1, x2, y2, level, output_row, 0), one row per
+ * workgroup in visiting order (level < 0: padding row, its output row is zero-filled).  Saves the three dependent global
+ * loads (order -> level -> roi) at the head of every workgroup.  sampling_ratio > 0 only. */
+int dtc_roi_align_forward_packed(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,
+                                 const float* roi_desc, int n_rois, int pooled_h, int pooled_w, int sampling_ratio, void* out,
+                                 int out_dtype, dtc_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * A5  Hard NMS
  * --------------------------------------------------------------------------------------------------------------- */
@@ -152,11 +159,14 @@ int dtc_gather_kept(const float* sorted_boxes, const float* sorted_scores, int n
  *   rois_by_level [B,topN,4] + level_counts int32 [B,k_max-k_min+1] = the reference's per-level lists, concatenated;
  *   idx_restore int32 [B,topN] = the reference's rois_idx_restore (:127);
  *   roi_order int32 [B,topN] (nullable) = global row ids b*topN + r sorted by (level, y centre): the visiting order for
- *   dtc_roi_align_forward_ordered (a performance hint, not part of the reference's semantics). */
+ *   dtc_roi_align_forward_ordered (a performance hint, not part of the reference's semantics);
+ *   roi_desc float32 [B,topN,8] (nullable) = the same rois packed in visiting order as (batch,x1,y1,x2,y2,level,row,0) for
+ *   dtc_roi_align_forward_packed. */
 int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_scores, const int32_t* in_counts, int batch,
                                int n_in_levels, int in_stride, int post_nms_top_n, int k_min, int k_max, float* rois5,
                                float* roi_scores, int32_t* roi_levels, int32_t* n_out, float* rois_by_level,
-                               int32_t* level_counts, int32_t* idx_restore, int32_t* roi_order, dtc_stream_t stream);
+                               int32_t* level_counts, int32_t* idx_restore, int32_t* roi_order, float* roi_desc,
+                               dtc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * A8  Detection post-processing
