@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=4, help="images of the same workload timed on the CPU oracle")
     ap.add_argument("--kernel-iters", type=int, default=20)
+    ap.add_argument("--split", type=int, default=1, help="sub-batches run on separate HIP streams inside one hipGraph")
     return ap.parse_args()
 
 
@@ -83,10 +84,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from detectorch_amd import hip
-    from detectorch_amd.pipeline import FpnRegionPath, synthetic_batch
+    from detectorch_amd.pipeline import FpnRegionPath, OverlappedRegionPath, synthetic_batch
     hip.lib()   # fails loudly if the native library is missing
     fdt = torch.float16 if a.fp16 else torch.float32
-    path = FpnRegionPath(a.batch, dev, feat_dtype=fdt)
+    if a.split > 1 and a.batch % a.split == 0:
+        path = OverlappedRegionPath(a.batch, dev, n_split=a.split, feat_dtype=fdt)
+    else:
+        path = FpnRegionPath(a.batch, dev, feat_dtype=fdt)
     inputs = synthetic_batch(a.batch, dev, seed=3000 + rank, feat_dtype=fdt, channels_last=a.channels_last)
     path.bind(*inputs)
     gather = None
@@ -153,7 +157,7 @@ def main():
                                    "(268569 anchors) -> 1000 rois, 4-level RoIAlign 7x7 sr2 C256, 81-class postprocess, "
                                    "RoIAlign 14x14 mask branch, 28x28 mask paste",
                        "images_per_gpu_per_step": a.batch, "global_batch": a.batch * world, "rois_per_image": 1000,
-                       "feature_layout": "NHWC" if a.channels_last else "NCHW", "launch": "eager" if a.eager else "hipGraph",
+                       "feature_layout": "NHWC" if a.channels_last else "NCHW", "launch": ("eager" if a.eager else "hipGraph") + (", %d sub-batches on %d streams" % (a.split, a.split) if isinstance(path, OverlappedRegionPath) else ""),
                        "parallelism": "images sharded over %d GPU(s); all_gather of detections" % world,
                        "not_in_path": "ResNet-50/FPN convs and box/mask-head GEMMs (MIOpen/hipBLASLt), outputs synthetic"},
             "roofline": {"bound": "hbm", "kernel": "roi_align_fwd (box head, 4 levels, %d rois)" % (a.batch * 1000),

@@ -168,6 +168,74 @@ class FpnRegionPath:
         return out
 
 
+class OverlappedRegionPath:
+    """The same hot path with the batch split into `n_split` sub-batches that run on separate HIP streams inside ONE
+    hipGraph (fork/join).  The path alternates chip-filling RoIAlign launches with short latency-bound kernels (radix
+    select, NMS reduce, collect, detection finalize) that occupy a handful of CUs; with two sub-batches in flight the
+    small kernels of one overlap the RoIAlign of the other instead of serialising behind it."""
+
+    def __init__(self, batch, device, n_split=2, **kw):
+        assert batch % n_split == 0
+        self.B, self.dev, self.n = batch, device, n_split
+        self.sub = [FpnRegionPath(batch // n_split, device, **kw) for _ in range(n_split)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n_split)]
+        self.graph = None
+        p0 = self.sub[0]
+        self.max_out, self.top_n, self.pad_h, self.pad_w = p0.max_out, p0.top_n, p0.pad_h, p0.pad_w
+
+    def bind(self, rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, scaling_factor, im_size):
+        k = self.B // self.n
+        for i, p in enumerate(self.sub):
+            sl = slice(i * k, (i + 1) * k)
+            p.bind([t[sl] for t in rpn_cls], [t[sl] for t in rpn_bbox], [t[sl] for t in feats], cls_score[sl], bbox_pred[sl],
+                   masks[i * k * p.max_out:(i + 1) * k * p.max_out], scaling_factor[sl], im_size[sl])
+        self.graph = None
+
+    def _launch(self):
+        cur = torch.cuda.current_stream(self.dev)
+        for st, p in zip(self.streams, self.sub):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                p._launch()
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def step(self, use_graph=True):
+        with torch.cuda.device(self.dev):
+            if not use_graph:
+                self._launch()
+                return
+            if self.graph is None:
+                self._launch()
+                torch.cuda.synchronize(self.dev)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch()
+                self.graph = g
+            self.graph.replay()
+
+    @property
+    def dets(self):
+        return torch.cat([p.dets for p in self.sub], 0)
+
+    @property
+    def det_count(self):
+        return torch.cat([p.det_count for p in self.sub], 0)
+
+    def _roi_align_box(self):
+        for p in self.sub:
+            p._roi_align_box()
+
+    def box_roialign_bytes(self):
+        return sum(p.box_roialign_bytes() for p in self.sub)
+
+    def results(self):
+        out = []
+        for p in self.sub:
+            out += p.results()
+        return out
+
+
 def synthetic_batch(batch, device, seed, channels=256, n_cls=81, top_n=1000, max_out=128, mask_res=28,
                     feat_dtype=torch.float32, channels_last=False):
     """COCO-shaped synthetic inputs of SURVEY.md section 8(d), generated on the device (random-init: there are no

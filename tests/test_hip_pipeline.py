@@ -29,3 +29,49 @@ def test_fpn_region_path_vs_oracle_chain(oracle, use_graph):
                                  im_size[b], path.pad_h, path.pad_w)
         assert chain.compare_with_gpu(path, b, ref, int(im_size[b, 0]), int(im_size[b, 1]))
         assert ref["dets"].shape[0] >= 100
+
+
+def test_cfg5_shape_2000_proposals_fp16_features(oracle):
+    """BASELINE cfg5: collect top-N = 2000 (the train-time constant of collect...py:86 / detector.py:207) and fp16 feature
+    maps.  Oracle = CPU loop on the fp16->fp32 up-cast maps; fp32-accumulated features stored as fp16 -> rel 1e-3."""
+    import chain
+    from detectorch_amd.pipeline import FpnRegionPath, synthetic_batch
+    dev = torch.device("cuda", 0)
+    B, C = 1, 8
+    path = FpnRegionPath(B, dev, channels=C, collect_top_n=2000, feat_dtype=torch.float16)
+    inputs = synthetic_batch(B, dev, seed=5000, channels=C, top_n=2000, feat_dtype=torch.float16)
+    path.bind(*inputs)
+    path.step(use_graph=False)
+    torch.cuda.synchronize()
+    rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, sf, im_size = [
+        [t.float().cpu().numpy() for t in x] if isinstance(x, list) else x.float().cpu().numpy() for x in inputs]
+    ref = chain.fpn_hot_path([c[0] for c in rpn_cls], [d[0] for d in rpn_bbox], [f[0:1] for f in feats], cls_score[0],
+                             bbox_pred[0], masks[:path.max_out], sf[0], im_size[0], path.pad_h, path.pad_w, top_n=2000)
+    n = int(path.n_rois[0])
+    assert n == ref["rois"].shape[0] and n > 1000
+    assert np.array_equal(path.rois5[0, :n, 1:].cpu().numpy(), ref["rois"])
+    assert np.array_equal(path.roi_levels[0, :n].cpu().numpy(), ref["roi_levels"])
+    got = path.box_feats[:n].float().cpu().numpy()
+    assert np.allclose(got, ref["box_feats"], rtol=1e-3, atol=1e-3)
+    D = min(int(path.det_count[0]), path.max_out)
+    assert np.array_equal(path.dets[0, :D].cpu().numpy(), ref["dets"][:D])
+
+
+def test_overlapped_split_equals_single(oracle):
+    """Two sub-batches on two streams inside one hipGraph give exactly the single-stream result."""
+    from detectorch_amd.pipeline import FpnRegionPath, OverlappedRegionPath, synthetic_batch
+    dev = torch.device("cuda", 0)
+    B, C = 4, 8
+    inputs = synthetic_batch(B, dev, seed=3100, channels=C)
+    one = FpnRegionPath(B, dev, channels=C)
+    one.bind(*inputs)
+    one.step(use_graph=True)
+    two = OverlappedRegionPath(B, dev, n_split=2, channels=C)
+    two.bind(*inputs)
+    two.step(use_graph=True)
+    two.step(use_graph=True)
+    torch.cuda.synchronize()
+    assert torch.equal(one.det_count, two.det_count)
+    for b in range(B):
+        n = min(int(one.det_count[b]), one.max_out)
+        assert torch.equal(one.dets[b, :n], two.dets[b, :n])
