@@ -133,6 +133,8 @@ struct FinParams {
   int32_t* det_count;         // [B]
 };
 
+constexpr int kFinStage = 6144;   // kept entries staged in LDS (ordered score + class/candidate id); more -> global path
+
 __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) {
   __shared__ uint32_t h[2048];
   __shared__ uint32_t sh[2];
@@ -140,16 +142,37 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
   __shared__ int ccnt[kFinMaxCls];
   __shared__ int coff[kFinMaxCls + 1];
   __shared__ uint64_t bitmap[kFinThreads / 64][64];  // per wave: up to 4096 candidates per class
+  __shared__ uint32_t st_key[kFinStage];             // ordered score of kept entry f
+  __shared__ uint32_t st_cq[kFinStage];              // candidate index q of kept entry f
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nseg = p.n_cls - 1;
   const int seg0 = b * nseg;
+  if (tid < nseg) ccnt[tid] = p.keep_count[seg0 + tid];
+  __syncthreads();
   if (tid == 0) {
     int acc = 0;
-    for (int c = 0; c < nseg; c++) { koff[c] = acc; acc += p.keep_count[seg0 + c]; }
+    for (int c = 0; c < nseg; c++) { koff[c] = acc; acc += ccnt[c]; }
     koff[nseg] = acc;
   }
   __syncthreads();
   const int total = koff[nseg];
+  const bool staged = total <= kFinStage;
+  // kept entry f of this image -> (ordered score, candidate index q, class c)
+  auto fetch = [&](int c, int e, uint32_t& o, int& q) {
+    const int seg = seg0 + c;
+    q = p.q_of_k[(size_t)seg * p.R + p.keep[(size_t)seg * p.R + e]];
+    o = float_to_ordered(p.q_scores[(size_t)seg * p.R + q]);
+  };
+  if (staged) {   // three dependent global loads per entry, paid once, in parallel; every later phase runs from LDS
+    for (int f = tid; f < total; f += kFinThreads) {
+      int lo = 0, hi = nseg;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (koff[mid] <= f) lo = mid; else hi = mid; }
+      uint32_t o; int q;
+      fetch(lo, f - koff[lo], o, q);
+      st_key[f] = o; st_cq[f] = (uint32_t)q;
+    }
+    __syncthreads();
+  }
   // ---- per-image limit (result_utils.py:154-163): threshold = max_det-th largest kept score ----
   uint32_t T = 0;  // ordered-key threshold; 0 == keep everything
   if (p.max_det > 0 && total > p.max_det) {
@@ -158,11 +181,13 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
       for (int i = tid; i < 2048; i += kFinThreads) h[i] = 0;
       __syncthreads();
       for (int f = tid; f < total; f += kFinThreads) {
-        int lo = 0, hi = nseg;  // class c with koff[c] <= f < koff[c+1]
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (koff[mid] <= f) lo = mid; else hi = mid; }
-        const int seg = seg0 + lo, e = f - koff[lo];
-        const int q = p.q_of_k[(size_t)seg * p.R + p.keep[(size_t)seg * p.R + e]];
-        const uint32_t o = float_to_ordered(p.q_scores[(size_t)seg * p.R + q]);
+        uint32_t o;
+        if (staged) o = st_key[f];
+        else {
+          int lo = 0, hi = nseg;
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (koff[mid] <= f) lo = mid; else hi = mid; }
+          int q; fetch(lo, f - koff[lo], o, q);
+        }
         if (pass == 0) atomicAdd(&h[o >> 21], 1u);
         else if (pass == 1) { if ((o >> 21) == prefix) atomicAdd(&h[(o >> 10) & 2047u], 1u); }
         else { if ((o >> 10) == prefix) atomicAdd(&h[o & 1023u], 1u); }
@@ -176,15 +201,17 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
     T = prefix;
   }
   // ---- pass A: survivors per class ----
+  __syncthreads();
   for (int c = wv; c < nseg; c += kFinThreads / 64) {
-    const int seg = seg0 + c, nk = p.keep_count[seg];
+    const int nk = koff[c + 1] - koff[c];
     int cnt = 0;
     for (int e0 = 0; e0 < nk; e0 += 64) {
       const int e = e0 + lane;
       bool ok = false;
       if (e < nk) {
-        const int q = p.q_of_k[(size_t)seg * p.R + p.keep[(size_t)seg * p.R + e]];
-        ok = float_to_ordered(p.q_scores[(size_t)seg * p.R + q]) >= T;       // :161 `>=`
+        uint32_t o; int q;
+        if (staged) o = st_key[koff[c] + e]; else fetch(c, e, o, q);
+        ok = o >= T;                                                         // :161 `>=`
       }
       cnt += __builtin_popcountll(__ballot(ok));
     }
@@ -201,7 +228,7 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
   // ---- pass B: class-major, candidate(roi)-ascending output (:143 dets_j[keep], :165 vstack) ----
   const float sf = p.scale[b];
   for (int c = wv; c < nseg; c += kFinThreads / 64) {
-    const int seg = seg0 + c, nk = p.keep_count[seg];
+    const int seg = seg0 + c, nk = koff[c + 1] - koff[c];
     if (ccnt[c] == 0) continue;
     uint64_t* bm = bitmap[wv];
     bm[lane] = 0;
@@ -209,9 +236,9 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
     for (int e0 = 0; e0 < nk; e0 += 64) {
       const int e = e0 + lane;
       if (e < nk) {
-        const int q = p.q_of_k[(size_t)seg * p.R + p.keep[(size_t)seg * p.R + e]];
-        if (float_to_ordered(p.q_scores[(size_t)seg * p.R + q]) >= T && q < 4096)
-          atomicOr(reinterpret_cast<unsigned long long*>(&bm[q >> 6]), 1ull << (q & 63));
+        uint32_t o; int q;
+        if (staged) { o = st_key[koff[c] + e]; q = (int)st_cq[koff[c] + e]; } else fetch(c, e, o, q);
+        if (o >= T && q < 4096) atomicOr(reinterpret_cast<unsigned long long*>(&bm[q >> 6]), 1ull << (q & 63));
       }
     }
     __builtin_amdgcn_wave_barrier();

@@ -27,6 +27,7 @@ struct FpnParams {
   const float* in_scores;    // [B, L_in, P]     (NULL: no sort, take the first counts[b*L_in] rows of level 0 as they are)
   const int32_t* in_counts;  // [B, L_in]
   int L_in, P, top_n, k_min, k_max;
+  int inputs_sorted;         // every input list is already in (score desc) order (NMS output): merge by rank, no sort
   float* rois5;              // [B, top_n, 5]   (b, x1, y1, x2, y2) in collected (score) order
   float* roi_scores;         // [B, top_n]      (may be NULL)
   int32_t* roi_levels;       // [B, top_n]      level - k_min, or -1 for rows >= n_out[b]
@@ -59,7 +60,39 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(Fpn
   const int m = min(n, p.top_n);                                   // :104
   const float* boxes = p.in_boxes + (size_t)b * p.L_in * p.P * 4;
   int np2 = 2;
-  if (p.in_scores) {
+  if (p.in_scores && p.inputs_sorted) {
+    // L_in sorted lists -> rank of every element in the merged (score desc, concat index asc) order by binary search:
+    // rank(l, j) = j + sum over the other lists of #elements that precede it.  No barriers, no sort.
+    const float* scores = p.in_scores + (size_t)b * p.L_in * p.P;
+    float* sc = reinterpret_cast<float*>(keys + p.top_n);            // staged scores, concat layout
+    for (int i = tid; i < n; i += kFpnThreads) {
+      int l = 0;
+      for (int q = 1; q < p.L_in; q++) if (i >= in_off[q]) l = q;
+      sc[i] = scores[(size_t)l * p.P + (i - in_off[l])];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kFpnThreads) {
+      int l = 0;
+      for (int q = 1; q < p.L_in; q++) if (i >= in_off[q]) l = q;
+      const float s = sc[i];
+      int rank = i - in_off[l];
+      for (int q = 0; q < p.L_in; q++) {
+        if (q == l) continue;
+        // list q is non-increasing: count elements with score > s (q after l) or >= s (q before l: ties go to the
+        // smaller concat index)
+        int lo = in_off[q], hi = in_off[q + 1];
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          const float v = sc[mid];
+          const bool before = (q < l) ? (v >= s) : (v > s);
+          if (before) lo = mid + 1; else hi = mid;
+        }
+        rank += lo - in_off[q];
+      }
+      if (rank < p.top_n) keys[rank] = make_desc_key(s, (uint32_t)i);
+    }
+    __syncthreads();
+  } else if (p.in_scores) {
     const float* scores = p.in_scores + (size_t)b * p.L_in * p.P;
     np2 = next_pow2(n);
     for (int i = tid; i < np2; i += kFpnThreads) {
@@ -69,7 +102,6 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(Fpn
         for (int q = 1; q < p.L_in; q++) if (i >= in_off[q]) l = q;
         const int j = i - in_off[l];
         // key index = position in the concatenation (:95-97): ties resolve to the earlier level / earlier row.
-        // low 32 bits carry the concat index; the (level,row) source is recovered from it.
         k = make_desc_key(scores[(size_t)l * p.P + j], (uint32_t)i);
       }
       keys[i] = k;
@@ -147,7 +179,22 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(Fpn
       }
       keys[r] = k;
     }
-    block_bitonic_sort<kFpnThreads>(keys, np2o);
+    if (p.top_n <= 2048) {
+      // keys are unique: rank by counting (n^2 / 1024 broadcast LDS reads per thread, no barriers) beats 66 bitonic stages
+      __syncthreads();
+      uint64_t* sorted = keys + np2o;
+      for (int r = tid; r < p.top_n; r += kFpnThreads) {
+        const uint64_t k = keys[r];
+        int rank = 0;
+        for (int j = 0; j < p.top_n; j++) rank += keys[j] < k ? 1 : 0;
+        sorted[rank] = k;
+      }
+      __syncthreads();
+      for (int r = tid; r < p.top_n; r += kFpnThreads) keys[r] = sorted[r];
+      __syncthreads();
+    } else {
+      block_bitonic_sort<kFpnThreads>(keys, np2o);
+    }
     for (int i = tid; i < p.top_n; i += kFpnThreads) {
       const int r = (int)(uint32_t)keys[i];
       p.roi_order[(size_t)b * p.top_n + i] = b * p.top_n + r;
@@ -167,7 +214,7 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
                                        int n_in_levels, int in_stride, int post_nms_top_n, int k_min, int k_max,
                                        float* rois5, float* roi_scores, int32_t* roi_levels, int32_t* n_out,
                                        float* rois_by_level, int32_t* level_counts, int32_t* idx_restore,
-                                       int32_t* roi_order, float* roi_desc, dtc_stream_t stream) {
+                                       int32_t* roi_order, float* roi_desc, int inputs_sorted, dtc_stream_t stream) {
   if (batch < 0 || n_in_levels < 1 || n_in_levels > dtc::kFpnMaxLevels || in_stride < 1 || post_nms_top_n < 1 ||
       k_max < k_min || k_max - k_min + 1 > dtc::kFpnMaxLevels)
     return DTC_EINVAL;
@@ -178,11 +225,12 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
   if (in_scores && n_max > 16384) return DTC_EUNSUPPORTED;
   dtc::FpnParams p;
   p.in_boxes = in_boxes; p.in_scores = in_scores; p.in_counts = in_counts; p.L_in = n_in_levels; p.P = in_stride;
-  p.top_n = post_nms_top_n; p.k_min = k_min; p.k_max = k_max; p.rois5 = rois5; p.roi_scores = roi_scores;
+  p.top_n = post_nms_top_n; p.k_min = k_min; p.k_max = k_max; p.inputs_sorted = inputs_sorted; p.rois5 = rois5; p.roi_scores = roi_scores;
   p.roi_levels = roi_levels; p.n_out = n_out; p.rois_by_level = rois_by_level; p.level_counts = level_counts;
   p.idx_restore = idx_restore; p.roi_order = roi_order; p.roi_desc = roi_order ? roi_desc : nullptr;
   size_t smem = in_scores ? (size_t)dtc::next_pow2((int)n_max) * sizeof(uint64_t) : 16;
-  if (roi_order) { const size_t so = (size_t)dtc::next_pow2(post_nms_top_n) * sizeof(uint64_t); if (so > smem) smem = so; }
+  if (in_scores && inputs_sorted) smem = (size_t)post_nms_top_n * sizeof(uint64_t) + (size_t)n_max * sizeof(float) + 16;
+  if (roi_order) { const size_t so = (size_t)dtc::next_pow2(post_nms_top_n) * sizeof(uint64_t) * 2; if (so > smem) smem = so; }
   if (post_nms_top_n > 16384) return DTC_EUNSUPPORTED;
   if (smem > 64 * 1024) {
     static bool raised = false;

@@ -18,6 +18,7 @@ namespace dtc {
 
 constexpr int kPasteThreads = 256;
 constexpr int kMaxMaskSide = 64;  // M + 2 <= 64
+constexpr int kMaxTab = 4096;     // paste rectangle width + height served from LDS tables (larger: per-pixel math)
 
 struct PasteParams {
   const float* masks;         // [n_masks, n_cls, M, M]
@@ -52,8 +53,19 @@ __device__ __forceinline__ void paste_rect(const int eb[4], int im_h, int im_w, 
   if (r[3] < r[1]) r[3] = r[1];
 }
 
+// one axis of OpenCV's INTER_LINEAR coordinate rule (see the header): source index pair + fraction for destination index dd
+__device__ __forceinline__ void resize_axis(int dd, double scale, int S, int& s0, int& s1, float& f) {
+  f = (float)(((double)dd + 0.5) * scale - 0.5);
+  s0 = (int)floorf(f); f -= (float)s0;
+  if (s0 < 0) { s0 = 0; f = 0.f; }
+  if (s0 >= S - 1) { s0 = S - 1; f = 0.f; }
+  s1 = min(s0 + 1, S - 1);
+}
+
 __global__ __launch_bounds__(kPasteThreads) void mask_paste_kernel(PasteParams p) {
   __shared__ float pm[kMaxMaskSide * kMaxMaskSide];
+  __shared__ int tab_i[kMaxTab];
+  __shared__ float tab_f[kMaxTab];
   __shared__ long long red[kPasteThreads / 64];
   const int d = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int nd = min(p.det_count[b], p.max_out);
@@ -104,23 +116,36 @@ __global__ __launch_bounds__(kPasteThreads) void mask_paste_kernel(PasteParams p
   if (area == 0 || offset + area > p.per_image_capacity) return;
   uint8_t* out = p.crops + (size_t)b * p.per_image_capacity + offset;
   const double scale_x = (double)S / (double)w, scale_y = (double)S / (double)h;
-  for (long long i = tid; i < area; i += kPasteThreads) {
-    const int py = (int)(i / rw), px = (int)(i - (long long)py * rw);
-    const int dy = r[1] + py - eb[1], dx = r[0] + px - eb[0];   // coordinates inside the resized (w x h) mask (:209-213)
-    float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
-    int sy = (int)floorf(fy); fy -= (float)sy;
-    if (sy < 0) { sy = 0; fy = 0.f; }
-    if (sy >= S - 1) { sy = S - 1; fy = 0.f; }
-    const int sy1 = min(sy + 1, S - 1);
-    float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
-    int sx = (int)floorf(fx); fx -= (float)sx;
-    if (sx < 0) { sx = 0; fx = 0.f; }
-    if (sx >= S - 1) { sx = S - 1; fx = 0.f; }
-    const int sx1 = min(sx + 1, S - 1);
-    const float r0 = pm[sy * S + sx] * (1.f - fx) + pm[sy * S + sx1] * fx;
+  // Per-axis source index / fraction tables (the fp64 coordinate math is done once per row and once per column of the
+  // paste rectangle instead of once per pixel).  Entry: sx (low 16 bits), sx1 (high 16 bits), frac.
+  const bool use_tab = rw + rh <= kMaxTab;
+  if (use_tab) {
+    for (int t = tid; t < rw + rh; t += kPasteThreads) {
+      const bool is_x = t < rw;
+      const int dd = is_x ? (r[0] + t - eb[0]) : (r[1] + (t - rw) - eb[1]);   // coordinate inside the resized (w x h) mask
+      int s0, s1; float f;
+      resize_axis(dd, is_x ? scale_x : scale_y, S, s0, s1, f);
+      tab_i[t] = s0 | (s1 << 16);
+      tab_f[t] = f;
+    }
+    __syncthreads();
+  }
+  const int area_i = (int)area;   // <= im_h * im_w < 2^31: 32-bit index math (a 64-bit division per pixel dominated this loop)
+  for (int i = tid; i < area_i; i += kPasteThreads) {
+    const int py = i / rw, px = i - py * rw;
+    int sx, sx1, sy, sy1; float fx, fy;
+    if (use_tab) {
+      const int xi = tab_i[px], yi = tab_i[rw + py];
+      fx = tab_f[px]; fy = tab_f[rw + py];
+      sx = xi & 0xffff; sx1 = xi >> 16; sy = yi & 0xffff; sy1 = yi >> 16;
+    } else {
+      resize_axis(r[0] + px - eb[0], scale_x, S, sx, sx1, fx);
+      resize_axis(r[1] + py - eb[1], scale_y, S, sy, sy1, fy);
+    }
+    const float r0 = pm[sy * S + sx] * (1.f - fx) + pm[sy * S + sx1] * fx;     // horizontal pass
     const float r1 = pm[sy1 * S + sx] * (1.f - fx) + pm[sy1 * S + sx1] * fx;
-    const float v = r0 * (1.f - fy) + r1 * fy;
-    out[i] = v > p.thresh ? 1 : 0;                               // :203
+    const float v = r0 * (1.f - fy) + r1 * fy;                                  // vertical pass
+    out[i] = v > p.thresh ? 1 : 0;                                               // :203
   }
 }
 

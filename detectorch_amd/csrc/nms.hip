@@ -95,18 +95,16 @@ __global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4*
     const float xx2 = fminf(r.z, cbox.z), yy2 = fminf(r.w, cbox.w);          // :78-79
     const float w = fmaxf(0.0f, xx2 - xx1 + 1.f), h = fmaxf(0.0f, yy2 - yy1 + 1.f);  // :80-81
     const float inter = w * h;                                               // :82
-    // :83-84  `inter / (iarea + areas[j] - inter) >= thresh` with an IEEE float division.  Division-free and EXACT: the
-    // rounded quotient is >= thresh iff the real quotient is >= mid = (pred(thresh) + thresh)/2 (ties-to-even decides the
-    // equality case: cmp_mode 1 -> '>=', 2 -> '>'), i.e. inter >= mid * u; mid has 25 significant bits and u 24, so the
-    // double product is exact.  u <= 0 (degenerate boxes) or cmp_mode 0 (odd thresholds) take the division.
+    // :83-84  `inter / (iarea + areas[j] - inter) >= thresh` with an IEEE float division.  The division is only needed
+    // when inter is within 2^-21 (relative) of thresh * u: outside that band the outcome of the rounded quotient is
+    // already decided (the float products below carry <= 3 * 2^-24 relative error), so almost every pair costs three
+    // multiplies and two compares instead of the ~15-instruction division sequence.  u <= 0 (degenerate boxes) always
+    // takes the division, exactly like the reference.
     const float u = iarea + carea - inter;
-    bool ge;
-    if (cmp_mode != 0 && u > 0.f) {
-      const double lhs = (double)inter, rhs = mid * (double)u;
-      ge = cmp_mode == 1 ? (lhs >= rhs) : (lhs > rhs);
-    } else {
-      ge = fdiv(inter, u) >= thresh;
-    }
+    const float pu = thresh * u;
+    bool ge = inter >= pu * 1.00000048f;                 // 1 + 2^-21: certainly >= thresh
+    const bool lt = inter <= pu * 0.99999952f;           // 1 - 2^-21: certainly <  thresh
+    if (!(u > 0.f) || !(thresh > 0.f) || (!ge && !lt)) ge = fdiv(inter, u) >= thresh;
     const bool sup = col_ok && (col > rb * 64 + i) && ge;                    // :72 (_j > _i), :84
     const uint64_t word = __ballot(sup);
     if (lane == i) myword = word;

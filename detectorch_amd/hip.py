@@ -71,7 +71,7 @@ def lib():
     L.dtc_gather_kept.argtypes = [p, p, i, i, p, p, i, p, p, p]
     L.dtc_gather_kept.restype = i
     ll = C.c_longlong
-    L.dtc_fpn_collect_distribute.argtypes = [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p, p]
+    L.dtc_fpn_collect_distribute.argtypes = [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p, i, p]
     L.dtc_roi_align_forward_packed.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, i, i, i, p, i, p]
     L.dtc_roi_align_forward_packed.restype = i
     L.dtc_fpn_collect_distribute.restype = i
@@ -279,7 +279,7 @@ def generate_proposals(cls_probs, bbox_preds, anchors, feat_strides, im_h, im_w,
     return (out_boxes.view(B, nl, P, 4), out_scores.view(B, nl, P), kcnt.view(B, nl), pre_boxes, pre_scores, pre_counts)
 
 
-def fpn_collect_distribute(boxes, scores, counts, post_nms_top_n, k_min=2, k_max=5):
+def fpn_collect_distribute(boxes, scores, counts, post_nms_top_n, k_min=2, k_max=5, inputs_sorted=False):
     """dtc_fpn_collect_distribute.  boxes [B,L,P,4], scores [B,L,P] or None, counts int32 [B,L].
     -> dict(rois5 [B,T,5], roi_scores, roi_levels [B,T], n_out [B], rois_by_level [B,T,4], level_counts [B,nl],
             idx_restore [B,T])"""
@@ -306,7 +306,7 @@ def fpn_collect_distribute(boxes, scores, counts, post_nms_top_n, k_min=2, k_max
                                               out["roi_levels"].data_ptr(), out["n_out"].data_ptr(),
                                               out["rois_by_level"].data_ptr(), out["level_counts"].data_ptr(),
                                               out["idx_restore"].data_ptr(), out["roi_order"].data_ptr(),
-                                              out["roi_desc"].data_ptr(), stream_ptr(dev))
+                                              out["roi_desc"].data_ptr(), 1 if inputs_sorted else 0, stream_ptr(dev))
     check(rc, "dtc_fpn_collect_distribute")
     return out
 

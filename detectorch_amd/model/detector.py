@@ -279,7 +279,8 @@ class detector(nn.Module):
                 [1. / s for s in self.rpn_scales], h, w, [g.rpn_pre_nms_top_n for g in gens],
                 gens[0].rpn_post_nms_top_n, gens[0].rpn_nms_thresh)
             lv = [int(log2(1 / s)) for s in self.roi_spatial_scale]
-            fused = hip.fpn_collect_distribute(boxes, scores, counts, 1000, lv[0], lv[-1])   # collect...py:86
+            fused = hip.fpn_collect_distribute(boxes, scores, counts, 1000, lv[0], lv[-1],   # collect...py:86
+                                               inputs_sorted=True)
         if not self.use_fpn_body:
             roi_features = RoIAlignFunction.apply(img_features, preprocess_rois(rois), self.roi_height, self.roi_width,
                                                   self.roi_spatial_scale, self.roi_sampling_ratio)

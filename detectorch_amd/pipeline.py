@@ -104,7 +104,7 @@ class FpnRegionPath:
                                         B, 5, self.P, T, 2, 5, self.rois5.data_ptr(), self.roi_scores.data_ptr(),
                                         self.roi_levels.data_ptr(), self.n_rois.data_ptr(), self.rois_by_level.data_ptr(),
                                         self.level_counts.data_ptr(), self.idx_restore.data_ptr(),
-                                        self.roi_order.data_ptr(), self.roi_desc.data_ptr(), st), "fpn_collect")
+                                        self.roi_order.data_ptr(), self.roi_desc.data_ptr(), 1, st), "fpn_collect")
         self._roi_align_box(st)
         ck(L.dtc_postprocess_detections(self.rois5.data_ptr(), self.n_rois.data_ptr(), self.cls_score.data_ptr(),
                                         self.bbox_pred.data_ptr(), self.sf.data_ptr(), self.im_size.data_ptr(), B, T,
@@ -116,7 +116,7 @@ class FpnRegionPath:
         ck(L.dtc_fpn_collect_distribute(self.det_scaled.data_ptr(), None, self.det_count.data_ptr(), B, 1, D, D, 2, 5,
                                         self.m_rois5.data_ptr(), None, self.m_levels.data_ptr(), self.m_n.data_ptr(),
                                         self.m_by_level.data_ptr(), self.m_level_counts.data_ptr(),
-                                        self.m_restore.data_ptr(), self.m_order.data_ptr(), self.m_desc.data_ptr(), st),
+                                        self.m_restore.data_ptr(), self.m_order.data_ptr(), self.m_desc.data_ptr(), 0, st),
            "fpn_map_levels")
         self._roi_align_mask(st)
         ck(L.dtc_mask_paste(self.masks.data_ptr(), None, self.n_cls, self.M, self.dets.data_ptr(), self.det_count.data_ptr(),

@@ -161,12 +161,14 @@ int dtc_gather_kept(const float* sorted_boxes, const float* sorted_scores, int n
  *   roi_order int32 [B,topN] (nullable) = global row ids b*topN + r sorted by (level, y centre): the visiting order for
  *   dtc_roi_align_forward_ordered (a performance hint, not part of the reference's semantics);
  *   roi_desc float32 [B,topN,8] (nullable) = the same rois packed in visiting order as (batch,x1,y1,x2,y2,level,row,0) for
- *   dtc_roi_align_forward_packed. */
+ *   dtc_roi_align_forward_packed.
+ * inputs_sorted != 0 promises that every input list is already in descending score order (true for NMS output): the
+ * lists are then merged by rank instead of sorted. */
 int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_scores, const int32_t* in_counts, int batch,
                                int n_in_levels, int in_stride, int post_nms_top_n, int k_min, int k_max, float* rois5,
                                float* roi_scores, int32_t* roi_levels, int32_t* n_out, float* rois_by_level,
                                int32_t* level_counts, int32_t* idx_restore, int32_t* roi_order, float* roi_desc,
-                               dtc_stream_t stream);
+                               int inputs_sorted, dtc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * A8  Detection post-processing
