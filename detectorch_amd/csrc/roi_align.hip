@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_general(RoiAli
 // CTs in {64,32,16,8} is picked per RoI so that window + output slab fit the LDS budget (big windows -> fewer channels
 // per pass); a window that does not fit even with CTs = 8 takes the general path for that workgroup.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kLdsTableFloats = 512;       // 2 KB reserved for the axis tables: (PH + PW) * g <= 128 entries
+constexpr int kLdsTableFloats = 1024;      // 4 KB reserved for the axis tables: PH*gh + PW*gw <= 256 entries
 constexpr int kLdsPad = 4;
 
 constexpr int kStageMaxK = 16;              // 16-pixel chunks per thread: windows up to 16*4*16 = 1024 pixels
@@ -282,7 +282,7 @@ struct LdsAxis { int lo, hi; float l, h; };   // y: (row - y0) * ww * ctp ; x: (
 struct LdsGeom {
   const LdsAxis* ytab; const LdsAxis* xtab;
   float* slab; float* win;
-  int cts, bins, g, pooled_w, nc;
+  int cts, bins, gh, gw, pooled_w, nc;
   float count, inv_count;   // inv_count != 0 when count is a power of two (x * inv_count == x / count exactly)
 };
 
@@ -303,10 +303,10 @@ __device__ __forceinline__ void run_passes(Stager& st, const LdsGeom& G, const T
       const int ph = bin / G.pooled_w, pw = bin - ph * G.pooled_w;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       // reference order: for iy { for ix { acc += ... } }   (roi_align_cpu_loop.cpp:203-214)
-      for (int iy = 0; iy < G.g; iy++) {
-        const LdsAxis y = G.ytab[ph * G.g + iy];
-        for (int ix = 0; ix < G.g; ix++) {
-          const LdsAxis x = G.xtab[pw * G.g + ix];
+      for (int iy = 0; iy < G.gh; iy++) {
+        const LdsAxis y = G.ytab[ph * G.gh + iy];
+        for (int ix = 0; ix < G.gw; ix++) {
+          const LdsAxis x = G.xtab[pw * G.gw + ix];
           const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;       // roi_align_cpu_loop.cpp:95
           const float4 v1 = *reinterpret_cast<const float4*>(wq + y.lo + x.lo);
           const float4 v2 = *reinterpret_cast<const float4*>(wq + y.lo + x.hi);
@@ -379,15 +379,43 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   const float sw = rx1 * s, sh = ry1 * s, ew = rx2 * s, eh = ry2 * s;
   const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
   const float bin_h = fdiv(rh, (float)p.pooled_h), bin_w = fdiv(rw, (float)p.pooled_w);
-  const int g = p.sampling_ratio;
-  const float count = (float)(g * g);
-  const int ny = p.pooled_h * g, nx = p.pooled_w * g;
+  // sampling grid: fixed, or adaptive ceil(roi / pooled) per axis (roi_align_cpu_loop.cpp:166-170)
+  const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(rh, (float)p.pooled_h));
+  const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(rw, (float)p.pooled_w));
+  const float count = (float)(gh * gw);
+  const int ny = p.pooled_h * gh, nx = p.pooled_w * gw;
+  const bool tab_ok = (ny + nx) * 4 <= kLdsTableFloats;
   AxisEntry* xtab = ytab + ny;
-  for (int t = tid; t < ny + nx; t += kRoiAlignThreads) {
-    if (t < ny) ytab[t] = make_axis(sh, bin_h, t / g, t % g, g, L.height);
-    else { const int u = t - ny; xtab[u] = make_axis(sw, bin_w, u / g, u % g, g, L.width); }
+  if (tab_ok) {
+    for (int t = tid; t < ny + nx; t += kRoiAlignThreads) {
+      if (t < ny) ytab[t] = make_axis(sh, bin_h, t / gh, t % gh, gh, L.height);
+      else { const int u = t - ny; xtab[u] = make_axis(sw, bin_w, u / gw, u % gw, gw, L.width); }
+    }
   }
   __syncthreads();
+  const TIn* fbase = reinterpret_cast<const TIn*>(L.data) + (int64_t)b * L.stride_n;
+  if (!tab_ok) {
+    // huge adaptive grid (RoI much larger than the pooled size): per-output gather, geometry on the fly
+    for (int o = tid; o < nc * bins; o += kRoiAlignThreads) {
+      const int c = o / bins, bin = o - c * bins;
+      const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
+      const TIn* d = fbase + (int64_t)(c0 + c) * L.stride_c;
+      float acc = 0.f;
+      for (int iy = 0; iy < gh; iy++) {
+        const AxisEntry y = make_axis(sh, bin_h, ph, iy, gh, L.height);
+        const int64_t ylo = (int64_t)y.lo * L.stride_h, yhi = (int64_t)y.hi * L.stride_h;
+        for (int ix = 0; ix < gw; ix++) {
+          const AxisEntry x = make_axis(sw, bin_w, pw, ix, gw, L.width);
+          const int64_t xlo = (int64_t)x.lo * L.stride_w, xhi = (int64_t)x.hi * L.stride_w;
+          const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;
+          acc += w1 * to_f32<TIn>(d[ylo + xlo]) + w2 * to_f32<TIn>(d[ylo + xhi]) + w3 * to_f32<TIn>(d[yhi + xlo]) +
+                 w4 * to_f32<TIn>(d[yhi + xhi]);
+        }
+      }
+      out[o] = from_f32<TOut>(fdiv(acc, count));
+    }
+    return;
+  }
   const int y0 = ytab[0].lo, y1 = ytab[ny - 1].hi, x0 = xtab[0].lo, x1 = xtab[nx - 1].hi;
   const int ww = x1 - x0 + 1, wh = y1 - y0 + 1, npix = wh * ww;
   // sub-tile width: largest CTs whose window (+1 dummy pixel) + output slab fit
@@ -398,7 +426,6 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   for (int c = 32; c >= 8; c >>= 1)
     if (cts == 0 && npix <= kLdsMaxPix && npix * c <= 8192 &&
         (long long)(npix + 1) * (c + kLdsPad) + (long long)c * bins <= avail) cts = c;
-  const TIn* fbase = reinterpret_cast<const TIn*>(L.data) + (int64_t)b * L.stride_n;
   if (cts == 0) {
     // window too large for LDS: per-output gather straight from global (same arithmetic)
     for (int o = tid; o < nc * bins; o += kRoiAlignThreads) {
@@ -406,11 +433,11 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
       const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
       const TIn* d = fbase + (int64_t)(c0 + c) * L.stride_c;
       float acc = 0.f;
-      for (int iy = 0; iy < g; iy++) {
-        const AxisEntry y = ytab[ph * g + iy];
+      for (int iy = 0; iy < gh; iy++) {
+        const AxisEntry y = ytab[ph * gh + iy];
         const int64_t ylo = (int64_t)y.lo * L.stride_h, yhi = (int64_t)y.hi * L.stride_h;
-        for (int ix = 0; ix < g; ix++) {
-          const AxisEntry x = xtab[pw * g + ix];
+        for (int ix = 0; ix < gw; ix++) {
+          const AxisEntry x = xtab[pw * gw + ix];
           const int64_t xlo = (int64_t)x.lo * L.stride_w, xhi = (int64_t)x.hi * L.stride_w;
           const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;
           acc += w1 * to_f32<TIn>(d[ylo + xlo]) + w2 * to_f32<TIn>(d[ylo + xhi]) + w3 * to_f32<TIn>(d[yhi + xlo]) +
@@ -431,8 +458,9 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   G.ytab = yl; G.xtab = xl;
   G.slab = lds + kLdsTableFloats;                 // [cts][bins] output staging
   G.win = G.slab + cts * bins;                    // [npix + 1][cts + 4]  (cts*bins is a multiple of 4 -> 16 B aligned)
-  G.cts = cts; G.bins = bins; G.g = g; G.pooled_w = p.pooled_w; G.nc = nc; G.count = count;
-  G.inv_count = ((g & (g - 1)) == 0) ? fdiv(1.f, count) : 0.f;
+  G.cts = cts; G.bins = bins; G.gh = gh; G.gw = gw; G.pooled_w = p.pooled_w; G.nc = nc; G.count = count;
+  const int gg = gh * gw;
+  G.inv_count = ((gg & (gg - 1)) == 0) ? fdiv(1.f, count) : 0.f;
   const TIn* cbase = fbase + (int64_t)c0 * L.stride_c;
   if (L.stride_c == 1) {
     StagerNHWC<TIn> st; st.init(L, y0, x0, ww, wh, npix, cts);
@@ -506,9 +534,12 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   if (getenv("DTC_RA_CHBLOCK")) p.ch_block = atoi(getenv("DTC_RA_CHBLOCK"));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // fixed sampling grid with small tables -> LDS-staged kernel; adaptive sampling (sampling_ratio <= 0) -> general kernel
-  if (roi_desc && !(sampling_ratio > 0)) return DTC_EUNSUPPORTED;   // packed descriptors: LDS kernel only
-  const bool lds_ok = sampling_ratio > 0 && (pooled_h + pooled_w) * sampling_ratio * 4 <= dtc::kLdsTableFloats &&
+  // LDS-staged kernel for every pooled size whose output slab fits; adaptive sampling (sampling_ratio <= 0) included
+  // (tables sized per RoI, oversize grids/windows fall back per workgroup).  DTC_ROIALIGN_GENERAL=1 forces the plain
+  // per-output gather kernel (kept as the reference implementation of the arithmetic and for A/B measurements).
+  const bool lds_ok = (sampling_ratio <= 0 || (pooled_h + pooled_w) * sampling_ratio * 4 <= dtc::kLdsTableFloats) &&
                       (long long)pooled_h * pooled_w * 8 <= 4096 && getenv("DTC_ROIALIGN_GENERAL") == nullptr;
+  if (roi_desc && !lds_ok) return DTC_EUNSUPPORTED;   // packed descriptors are an LDS-kernel feature
   if (lds_ok) {
     if (in_dtype == DTC_F32 && out_dtype == DTC_F32) return dtc::launch_lds<float, float>(p, s);
     if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return dtc::launch_lds<__half, float>(p, s);
