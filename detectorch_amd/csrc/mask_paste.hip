@@ -18,6 +18,7 @@ namespace dtc {
 
 constexpr int kPasteThreads = 256;
 constexpr int kMaxMaskSide = 64;  // M + 2 <= 64
+constexpr int kPasteSplit = 8;    // workgroups per detection (row bands): one huge box no longer sets the kernel's duration
 constexpr int kMaxTab = 4096;     // paste rectangle width + height served from LDS tables (larger: per-pixel math)
 
 struct PasteParams {
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(kPasteThreads) void mask_paste_kernel(PasteParams p
   __shared__ int tab_i[kMaxTab];
   __shared__ float tab_f[kMaxTab];
   __shared__ long long red[kPasteThreads / 64];
-  const int d = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int d = blockIdx.x / kPasteSplit, band = blockIdx.x % kPasteSplit, b = blockIdx.y, tid = threadIdx.x;
   const int nd = min(p.det_count[b], p.max_out);
   const int im_h = (int)p.im_size[b * 2 + 0], im_w = (int)p.im_size[b * 2 + 1];
   // byte offset = sum of the paste-rect areas of the detections before this one (block 0 also publishes the total)
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(kPasteThreads) void mask_paste_kernel(PasteParams p
   __syncthreads();
   long long sum = 0;
   for (int q = 0; q < kPasteThreads / 64; q++) sum += red[q];
-  if (d == 0 && tid == 0) p.mask_bytes[b] = sum;
+  if (d == 0 && band == 0 && tid == 0) p.mask_bytes[b] = sum;
   if (d >= nd) return;
   const long long offset = (d == 0) ? 0 : sum;
 
@@ -94,11 +95,11 @@ __global__ __launch_bounds__(kPasteThreads) void mask_paste_kernel(PasteParams p
   paste_rect(eb, im_h, im_w, r);
   int w = eb[2] - eb[0] + 1, h = eb[3] - eb[1] + 1;      // :197-198
   w = max(w, 1); h = max(h, 1);                          // :199-200
-  if (tid < 4) {
+  if (band == 0 && tid < 4) {
     p.mask_boxes[((size_t)b * p.max_out + d) * 4 + tid] = eb[tid];
     p.mask_rects[((size_t)b * p.max_out + d) * 4 + tid] = r[tid];
   }
-  if (tid == 0) p.mask_offsets[(size_t)b * p.max_out + d] = offset;
+  if (band == 0 && tid == 0) p.mask_offsets[(size_t)b * p.max_out + d] = offset;
 
   // stage the zero-padded (M+2)x(M+2) mask of the detection's class (:185-195)
   const int S = p.M + 2;
@@ -130,8 +131,10 @@ __global__ __launch_bounds__(kPasteThreads) void mask_paste_kernel(PasteParams p
     }
     __syncthreads();
   }
-  const int area_i = (int)area;   // <= im_h * im_w < 2^31: 32-bit index math (a 64-bit division per pixel dominated this loop)
-  for (int i = tid; i < area_i; i += kPasteThreads) {
+  // this workgroup's band of rows; 32-bit index math (area <= im_h * im_w < 2^31; a 64-bit division per pixel dominated
+  // this loop before)
+  const int row0 = (int)((long long)rh * band / kPasteSplit), row1 = (int)((long long)rh * (band + 1) / kPasteSplit);
+  for (int i = row0 * rw + tid; i < row1 * rw; i += kPasteThreads) {
     const int py = i / rw, px = i - py * rw;
     int sx, sx1, sy, sy1; float fx, fy;
     if (use_tab) {
@@ -164,7 +167,7 @@ DTC_API int dtc_mask_paste(const float* masks, const int32_t* mask_index, int n_
   p.n_cls = n_cls; p.M = M; p.max_out = max_out; p.cls_specific = cls_specific_mask; p.thresh = thresh_binarize;
   p.crops = crops; p.per_image_capacity = per_image_capacity; p.mask_boxes = mask_boxes; p.mask_rects = mask_rects;
   p.mask_offsets = mask_offsets; p.mask_bytes = mask_bytes;
-  hipLaunchKernelGGL(dtc::mask_paste_kernel, dim3(max_out, batch), dim3(dtc::kPasteThreads), 0,
+  hipLaunchKernelGGL(dtc::mask_paste_kernel, dim3(max_out * dtc::kPasteSplit, batch), dim3(dtc::kPasteThreads), 0,
                      reinterpret_cast<hipStream_t>(stream), p);
   DTC_CHECK_LAUNCH();
   return DTC_OK;

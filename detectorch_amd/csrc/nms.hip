@@ -62,55 +62,64 @@ constexpr int kMaskWaves = 4;  // a workgroup = 4 wavefronts = 4 consecutive col
 
 __global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4* __restrict__ boxes,
                                                                    const int32_t* __restrict__ counts, int n_stride,
-                                                                   int ncb_stride, float thresh, double mid,
-                                                                   int cmp_mode, uint64_t* __restrict__ mask) {
+                                                                   int ncb_stride, float thresh,
+                                                                   uint64_t* __restrict__ mask) {
+  // grid = (GX, 1, n_seg): a workgroup walks the (row block, column-block group) tiles of ITS segment with stride GX.
+  // The iteration space is derived from the segment's actual count, so the 600+ class segments of a detection batch
+  // (mostly <= 64 candidates = one tile) cost one short workgroup each instead of a worst-case 16x4 tile grid whose
+  // empty workgroups dominated the launch (measured 90 us -> see profiles/).
   __shared__ float4 rbox_s[64];
   __shared__ float rarea_s[64];
-  const int rb = blockIdx.y, s = blockIdx.z;
-  const int cb0 = blockIdx.x * kMaskWaves;
-  if (cb0 + kMaskWaves - 1 < rb) return;                      // whole workgroup below the diagonal
+  const int s = blockIdx.z;
   const int n = counts ? min(counts[s], n_stride) : n_stride;
-  if (rb * 64 >= n) return;
+  const int ncb = (n + 63) >> 6;
+  const int ncg = (ncb + kMaskWaves - 1) / kMaskWaves;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float4* B = boxes + (size_t)s * n_stride;
-  if (wv == 0) {
-    const int row = rb * 64 + lane;
-    const float4 rbx = row < n ? B[row] : make_float4(0.f, 0.f, -1.f, -1.f);
-    rbox_s[lane] = rbx;
-    rarea_s[lane] = box_area(rbx);
-  }
-  __syncthreads();
-  const int cb = cb0 + wv;
-  if (cb < rb || cb * 64 >= n) return;
-  const int col = cb * 64 + lane;
-  const bool col_ok = col < n;
-  const float4 cbox = col_ok ? B[col] : make_float4(0.f, 0.f, -1.f, -1.f);
-  const float carea = box_area(cbox);
-  uint64_t myword = 0;
+  for (int t = blockIdx.x; t < ncb * ncg; t += gridDim.x) {
+    const int rb = t / ncg, cg = t - rb * ncg;
+    const int cb0 = cg * kMaskWaves;
+    if (cb0 + kMaskWaves - 1 < rb) continue;                  // whole group below the diagonal (uniform)
+    __syncthreads();                                          // previous tile's readers are done with rbox_s
+    if (wv == 0) {
+      const int row = rb * 64 + lane;
+      const float4 rbx = row < n ? B[row] : make_float4(0.f, 0.f, -1.f, -1.f);
+      rbox_s[lane] = rbx;
+      rarea_s[lane] = box_area(rbx);
+    }
+    __syncthreads();
+    const int cb = cb0 + wv;
+    if (cb < rb || cb >= ncb) continue;                       // per-wave skip; barriers above are reached by all waves
+    const int col = cb * 64 + lane;
+    const bool col_ok = col < n;
+    const float4 cbox = col_ok ? B[col] : make_float4(0.f, 0.f, -1.f, -1.f);
+    const float carea = box_area(cbox);
+    uint64_t myword = 0;
 #pragma unroll 8
-  for (int i = 0; i < 64; i++) {
-    const float4 r = rbox_s[i];                                // uniform address: LDS broadcast
-    const float iarea = rarea_s[i];
-    const float xx1 = fmaxf(r.x, cbox.x), yy1 = fmaxf(r.y, cbox.y);          // cython_nms.pyx:76-77
-    const float xx2 = fminf(r.z, cbox.z), yy2 = fminf(r.w, cbox.w);          // :78-79
-    const float w = fmaxf(0.0f, xx2 - xx1 + 1.f), h = fmaxf(0.0f, yy2 - yy1 + 1.f);  // :80-81
-    const float inter = w * h;                                               // :82
-    // :83-84  `inter / (iarea + areas[j] - inter) >= thresh` with an IEEE float division.  The division is only needed
-    // when inter is within 2^-21 (relative) of thresh * u: outside that band the outcome of the rounded quotient is
-    // already decided (the float products below carry <= 3 * 2^-24 relative error), so almost every pair costs three
-    // multiplies and two compares instead of the ~15-instruction division sequence.  u <= 0 (degenerate boxes) always
-    // takes the division, exactly like the reference.
-    const float u = iarea + carea - inter;
-    const float pu = thresh * u;
-    bool ge = inter >= pu * 1.00000048f;                 // 1 + 2^-21: certainly >= thresh
-    const bool lt = inter <= pu * 0.99999952f;           // 1 - 2^-21: certainly <  thresh
-    if (!(u > 0.f) || !(thresh > 0.f) || (!ge && !lt)) ge = fdiv(inter, u) >= thresh;
-    const bool sup = col_ok && (col > rb * 64 + i) && ge;                    // :72 (_j > _i), :84
-    const uint64_t word = __ballot(sup);
-    if (lane == i) myword = word;
+    for (int i = 0; i < 64; i++) {
+      const float4 r = rbox_s[i];                                // uniform address: LDS broadcast
+      const float iarea = rarea_s[i];
+      const float xx1 = fmaxf(r.x, cbox.x), yy1 = fmaxf(r.y, cbox.y);          // cython_nms.pyx:76-77
+      const float xx2 = fminf(r.z, cbox.z), yy2 = fminf(r.w, cbox.w);          // :78-79
+      const float w = fmaxf(0.0f, xx2 - xx1 + 1.f), h = fmaxf(0.0f, yy2 - yy1 + 1.f);  // :80-81
+      const float inter = w * h;                                               // :82
+      // :83-84  `inter / (iarea + areas[j] - inter) >= thresh` with an IEEE float division.  The division is only needed
+      // when inter is within 2^-21 (relative) of thresh * u: outside that band the outcome of the rounded quotient is
+      // already decided (the float products below carry <= 3 * 2^-24 relative error), so almost every pair costs three
+      // multiplies and two compares instead of the ~15-instruction division sequence.  u <= 0 (degenerate boxes) always
+      // takes the division, exactly like the reference.
+      const float u = iarea + carea - inter;
+      const float pu = thresh * u;
+      bool ge = inter >= pu * 1.00000048f;                 // 1 + 2^-21: certainly >= thresh
+      const bool lt = inter <= pu * 0.99999952f;           // 1 - 2^-21: certainly <  thresh
+      if (!(u > 0.f) || !(thresh > 0.f) || (!ge && !lt)) ge = fdiv(inter, u) >= thresh;
+      const bool sup = col_ok && (col > rb * 64 + i) && ge;                    // :72 (_j > _i), :84
+      const uint64_t word = __ballot(sup);
+      if (lane == i) myword = word;
+    }
+    const int row = rb * 64 + lane;
+    if (row < n) mask[((size_t)s * n_stride + row) * ncb_stride + cb] = myword;
   }
-  const int row = rb * 64 + lane;
-  if (row < n) mask[((size_t)s * n_stride + row) * ncb_stride + cb] = myword;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -238,23 +247,14 @@ DTC_API int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg,
   const int ncb = (n_stride + 63) / 64;
   if (ncb > 64 * 4) return DTC_EUNSUPPORTED;  // > 16384 boxes per segment
   uint64_t* mask = reinterpret_cast<uint64_t*>(workspace);
-  // exact division-free threshold test (see nms_mask_kernel): only for normal positive thresholds
-  double mid = 0.0;
-  int cmp_mode = 0;
-  // Measured on MI355X: the fp64 convert/multiply/compare sequence is SLOWER than the IEEE float division here
-  // (nms_mask 87 -> 102 us for 40 RPN segments), so the exact division-free test stays disabled (cmp_mode 0).
-  if (getenv("DTC_NMS_NODIV") && thresh > 1e-30f && thresh < 1e30f) {
-    uint32_t tb;
-    memcpy(&tb, &thresh, sizeof(tb));
-    const uint32_t pb = tb - 1;                       // pred(thresh) for a positive normal float
-    float tp;
-    memcpy(&tp, &pb, sizeof(tp));
-    mid = ((double)thresh + (double)tp) * 0.5;
-    cmp_mode = (tb & 1u) == 0 ? 1 : 2;                // tie rounds to the even mantissa
-  }
-  hipLaunchKernelGGL(dtc::nms_mask_kernel, dim3((ncb + dtc::kMaskWaves - 1) / dtc::kMaskWaves, ncb, n_seg),
-                     dim3(64 * dtc::kMaskWaves), 0, s, reinterpret_cast<const float4*>(boxes), counts, n_stride, ncb, thresh,
-                     mid, cmp_mode, mask);
+  // workgroups per segment: all tile groups when there are few segments (RPN: 40 x 64), a handful when there are many
+  // (detections: 640 class segments, mostly one tile each)
+  const int groups = ncb * ((ncb + dtc::kMaskWaves - 1) / dtc::kMaskWaves);
+  int gx = 4096 / n_seg;
+  if (gx < 1) gx = 1;
+  if (gx > groups) gx = groups;
+  hipLaunchKernelGGL(dtc::nms_mask_kernel, dim3(gx, 1, n_seg), dim3(64 * dtc::kMaskWaves), 0, s,
+                     reinterpret_cast<const float4*>(boxes), counts, n_stride, ncb, thresh, mask);
   DTC_CHECK_LAUNCH();
   hipLaunchKernelGGL(dtc::nms_reduce_kernel, dim3(n_seg), dim3(64), 0, s, mask, counts, n_stride, ncb, max_keep, keep,
                      keep_stride, keep_count);

@@ -108,3 +108,26 @@ def test_caffe2_blob_names():
     assert _caffe2_name("layer3.5.bn3.weight") == "res4_5_branch2c_bn_s"
     assert _caffe2_name("layer2.0.downsample.0.weight") == "res3_0_branch1_w"
     assert _caffe2_name("layer2.0.downsample.1.bias") == "res3_0_branch1_bn_b"
+
+
+def test_argument_validation_returns_error_codes_without_touching_the_gpu():
+    """Every entry validates its arguments before the first HIP call: bad calls return DTC_E* (negative), never crash."""
+    from detectorch_amd import hip
+    L = hip.lib()
+    EINVAL, EUNSUP = -1, -4
+    lv = (hip.FeatLevel * 1)()
+    assert L.dtc_roi_align_forward(None, 1, 256, 0, None, 5, None, 10, 7, 7, 2, None, 0, None) == EINVAL
+    assert L.dtc_roi_align_forward(lv, 1, 256, 0, None, 3, None, 10, 7, 7, 2, None, 0, None) == EINVAL      # roi_cols
+    assert L.dtc_roi_align_forward(lv, 9, 256, 0, None, 5, None, 0, 7, 7, 2, None, 0, None) == EINVAL       # n_levels
+    assert L.launch_roi_align_forward_hip(0, None, None, 1.0, 0, 1, 1, 7, 7, 2, None, None) == 0            # reference: 0 = error
+    assert L.dtc_nms(None, -1, 0.5, None, 0, None, None, None) == EINVAL
+    assert L.dtc_nms(None, 20000, 0.5, None, 0, None, ctypes.c_void_p(8), None) == EUNSUP                 # n > 16384
+    assert L.dtc_soft_nms(None, 10, 0.5, 0.3, 0.001, 7, None, None, ctypes.c_void_p(8), None) == EINVAL     # method
+    assert L.dtc_postprocess_detections(None, None, None, None, None, None, 1, 0, 81, 10., 10., 5., 5., .05, .5, 100,
+                                        None, 0, None, None, None, None, 128, None) == EINVAL
+    assert L.dtc_mask_paste(None, None, 81, 100, None, None, None, 1, 10, 0.5, 1, None, 0, None, None, None, None, None) == EINVAL
+    assert L.dtc_fpn_collect_distribute(None, None, None, 1, 9, 10, 10, 2, 5, None, None, None, None, None, None, None,
+                                        None, None, 0, None) == EINVAL
+    lvl = (hip.RpnLevel * 1)()
+    assert L.dtc_rpn_topk_decode_workspace_bytes(lvl, 1, 1, 0) == 0                                        # invalid level -> 0
+    assert L.dtc_rpn_topk_decode(None, 1, 1, 800., 1333., 0., None, 0, None, None, None, 0, None) == EINVAL
