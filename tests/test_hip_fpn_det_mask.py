@@ -197,3 +197,29 @@ def test_mask_paste_vs_oracle_and_segm_results(hip, oracle):
         assert np.array_equal(got, ref), d
         n_ones += int(ref.sum())
     assert n_ones > 1000
+
+
+def test_zero_detections_everywhere(hip, oracle):
+    """All class scores below the 0.05 threshold: empty results must flow through every stage (result_utils.py:126-168
+    with no survivors; the eval loop `continue`s at eval_mask_FPN.ipynb:244)."""
+    from detectorch_amd.utils import result_utils
+    rs = synth.rng(5, 404)
+    R = 64
+    rois = synth.make_rois(rs, R)
+    cls = np.full((R, 81), 0.01, np.float32)
+    cls[:, 0] = 0.2
+    dl = (rs.standard_normal((R, 324)) * 0.1).astype(np.float32)
+    sc, bx, cb = result_utils.postprocess_output(cu(rois), 1.6, torch.tensor([500., 833., 3.]), cu(cls), cu(dl))
+    assert sc.shape == (0,) and bx.shape == (0, 4) and all(len(cb[j]) == 0 for j in range(1, 81))
+    rd, _ = oracle.postprocess_detections(rois, 1.6, (500., 833.), cls, dl)
+    assert rd.shape[0] == 0
+    # batched kernel: one empty image next to a non-empty one
+    cls2, dl2 = synth.make_head_outputs(rs, R)
+    dets, roi, scaled, cnt = hip.postprocess_detections(
+        cu(np.concatenate([np.zeros((2, R, 1), np.float32), np.stack([rois, rois])], 2)), None, cu(np.stack([cls, cls2])),
+        cu(np.stack([dl, dl2])), cu(np.array([1.6, 1.6], np.float32)), cu(np.array([[500, 833], [500, 833]], np.float32)))
+    assert int(cnt[0]) == 0 and int(cnt[1]) == oracle.postprocess_detections(rois, 1.6, (500., 833.), cls2, dl2)[0].shape[0]
+    out = hip.mask_paste(torch.zeros((2 * 128, 81, 28, 28), device="cuda"), dets, cnt, cu(np.array([[500, 833], [500, 833]], np.float32)), 28, 1 << 20)
+    assert int(out["bytes"][0]) == 0
+    segms = result_utils.segm_results(cb, torch.zeros((0, 81, 28, 28), device="cuda"), bx, 500, 833, M=28)
+    assert all(len(s) == 0 for s in segms)
