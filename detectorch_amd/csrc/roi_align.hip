@@ -613,6 +613,205 @@ static int launch_nhwc(const RoiAlignParams& p, hipStream_t stream) {
   return DTC_OK;
 }
 
+static int lds_bytes();
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA kernel (NCHW fp32 features, the reference's layout): the box/mask-head fast path.
+//
+// The register-prefetch kernel above is bound by bytes-in-flight: ~32 prefetch registers per lane x 12 waves per CU cover
+// ~1.5 us of L2 latency and no more (PMC: 54 % of wave-cycles waiting).  Here the window is staged with
+// `global_load_lds_dword` (direct global->LDS DMA): no staging VGPRs, no ds_write pass, no per-element VALU, and a whole
+// next sub-tile (~20 KB per workgroup, x3 workgroups per CU) is in flight while the current one is computed.
+//   * LDS image is CHANNEL-major: plane c = [PS] floats, PS = 64*ceil(npix/64) + 1.  A DMA instruction writes 64 consecutive
+//     floats = 64 consecutive window pixels of one plane (lane-linear destination, per-lane source address), i.e. 2-3
+//     coalesced row pieces per instruction;
+//   * compute: lane <-> (channel, bin): a tap is one ds_read_b32 at  ch*PS + pixel_offset ; PS is odd, so the CT channels
+//     of a bin hit distinct banks.  Weights and offsets come from the per-axis LDS tables;
+//   * double buffer: DMA of sub-tile i+1 is issued right after the barrier that publishes sub-tile i; every wave waits
+//     vmcnt(0) before that barrier (LDS-DMA data is ordered for a ds_read only by the issuer's vmcnt + a barrier).
+// Arithmetic and accumulation order are those of the reference CPU loop: bit-identical output.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kDmaMaxChunks = 16;   // 64-pixel chunks per plane: windows up to 1024 pixels
+
+__device__ __forceinline__ void dma_load_dword(const float* gptr, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
+template <typename TOut>
+__global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_dma(RoiAlignParams p, int lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* lds = reinterpret_cast<float*>(smem);
+  AxisEntry* ytab = reinterpret_cast<AxisEntry*>(smem);
+  const int nct = ceil_div(p.channels, p.ch_block);
+  const int ri = blockIdx.x / nct;
+  const int c0 = (blockIdx.x - ri * nct) * p.ch_block;
+  const int nc = min(p.ch_block, p.channels - c0);
+  const int bins = p.pooled_h * p.pooled_w;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int r, lvl, b = 0;
+  float rx1, ry1, rx2, ry2;
+  if (p.roi_desc) {
+    const float4 d0 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2];
+    const float4 d1 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2 + 1];
+    b = (int)d0.x; rx1 = d0.y; ry1 = d0.z; rx2 = d0.w; ry2 = d1.x; lvl = (int)d1.y; r = (int)d1.z;
+  } else {
+    r = p.roi_order ? p.roi_order[ri] : ri;
+    lvl = p.roi_levels ? p.roi_levels[r] : 0;
+    const float* roi = p.rois + (size_t)r * p.roi_cols;
+    if (p.roi_cols == 5) { b = (int)roi[0]; roi++; }
+    rx1 = roi[0]; ry1 = roi[1]; rx2 = roi[2]; ry2 = roi[3];
+  }
+  TOut* out = reinterpret_cast<TOut*>(p.out) + ((size_t)r * p.channels + c0) * bins;
+  if (lvl < 0 || lvl >= p.n_levels) {
+    for (int o = tid; o < nc * bins; o += kRoiAlignThreads) out[o] = from_f32<TOut>(0.f);
+    return;
+  }
+  const dtc_feat_level L = p.lv[lvl];
+  const float s = L.spatial_scale;
+  const float sw = rx1 * s, sh = ry1 * s, ew = rx2 * s, eh = ry2 * s;
+  const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
+  const float bin_h = fdiv(rh, (float)p.pooled_h), bin_w = fdiv(rw, (float)p.pooled_w);
+  const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(rh, (float)p.pooled_h));
+  const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(rw, (float)p.pooled_w));
+  const float count = (float)(gh * gw);
+  const int gg = gh * gw;
+  const float inv_count = ((gg & (gg - 1)) == 0) ? fdiv(1.f, count) : 0.f;
+  const int ny = p.pooled_h * gh, nx = p.pooled_w * gw;
+  const bool tab_ok = (ny + nx) * 4 <= kLdsTableFloats;
+  AxisEntry* xtab = ytab + ny;
+  if (tab_ok) {
+    for (int t = tid; t < ny + nx; t += kRoiAlignThreads) {
+      if (t < ny) ytab[t] = make_axis(sh, bin_h, t / gh, t % gh, gh, L.height);
+      else { const int u = t - ny; xtab[u] = make_axis(sw, bin_w, u / gw, u % gw, gw, L.width); }
+    }
+  }
+  __syncthreads();
+  const float* fbase = reinterpret_cast<const float*>(L.data) + (int64_t)b * L.stride_n;
+  int y0 = 0, x0 = 0, ww = 1, wh = 1, npix = 0, ct = 0, nch = 0, PS = 0;
+  if (tab_ok) {
+    y0 = ytab[0].lo; x0 = xtab[0].lo;
+    ww = xtab[nx - 1].hi - x0 + 1; wh = ytab[ny - 1].hi - y0 + 1;
+    npix = ww * wh;
+    nch = (npix + 63) >> 6;
+    PS = nch * 64 + 1;
+#pragma unroll
+    for (int c = 32; c >= 8; c >>= 1)
+      if (ct == 0 && nch <= kDmaMaxChunks && kLdsTableFloats + c * bins + 2 * c * PS <= lds_floats) ct = c;
+  }
+  if (ct == 0) {
+    // oversize window / sampling grid: per-output gather straight from global (same arithmetic)
+    for (int o = tid; o < nc * bins; o += kRoiAlignThreads) {
+      const int c = o / bins, bin = o - c * bins;
+      const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
+      const float* d = fbase + (int64_t)(c0 + c) * L.stride_c;
+      float acc = 0.f;
+      for (int iy = 0; iy < gh; iy++) {
+        const AxisEntry y = tab_ok ? ytab[ph * gh + iy] : make_axis(sh, bin_h, ph, iy, gh, L.height);
+        const int64_t ylo = (int64_t)y.lo * L.stride_h, yhi = (int64_t)y.hi * L.stride_h;
+        for (int ix = 0; ix < gw; ix++) {
+          const AxisEntry x = tab_ok ? xtab[pw * gw + ix] : make_axis(sw, bin_w, pw, ix, gw, L.width);
+          const int64_t xlo = (int64_t)x.lo * L.stride_w, xhi = (int64_t)x.hi * L.stride_w;
+          const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;
+          acc += w1 * d[ylo + xlo] + w2 * d[ylo + xhi] + w3 * d[yhi + xlo] + w4 * d[yhi + xhi];
+        }
+      }
+      out[o] = from_f32<TOut>(fdiv(acc, count));
+    }
+    return;
+  }
+  __syncthreads();
+  // tables -> window-relative pixel offsets (in place)
+  LdsAxis* yl = reinterpret_cast<LdsAxis*>(ytab);
+  LdsAxis* xl = reinterpret_cast<LdsAxis*>(xtab);
+  if (tid < ny) { AxisEntry e = ytab[tid]; LdsAxis o; o.lo = (e.lo - y0) * ww; o.hi = (e.hi - y0) * ww; o.l = e.l; o.h = e.h; yl[tid] = o; }
+  else if (tid < ny + nx) { AxisEntry e = ytab[tid]; LdsAxis o; o.lo = e.lo - x0; o.hi = e.hi - x0; o.l = e.l; o.h = e.h; yl[tid] = o; }
+  float* slab = lds + kLdsTableFloats;            // [ct][bins]
+  float* buf0 = slab + ct * bins;                 // [ct][PS]
+  float* buf1 = buf0 + ct * PS;
+  // per-lane source offsets (elements inside one plane) of the window pixels this lane feeds, one per 64-pixel chunk
+  int32_t goff[kDmaMaxChunks];
+  {
+    const int q64 = 64 / ww, r64 = 64 - q64 * ww;
+    int pix = lane, py = lane / ww, px = lane - py * ww;
+#pragma unroll
+    for (int k = 0; k < kDmaMaxChunks; k++) {
+      const bool ok = pix < npix;
+      const int ly = ok ? py : wh - 1, lx = ok ? px : ww - 1;    // lanes past the window re-read its last pixel (pad area)
+      goff[k] = (int32_t)((int64_t)(y0 + ly) * L.stride_h + (int64_t)(x0 + lx) * L.stride_w);
+      pix += 64; px += r64; py += q64;
+      if (px >= ww) { px -= ww; py++; }
+    }
+  }
+  const float* cbase = fbase + (int64_t)c0 * L.stride_c;
+  auto issue = [&](int cs, float* buf) {
+    for (int c = wv; c < ct; c += kRoiAlignThreads / 64) {
+      const int cc = min(cs + c, nc - 1);                       // channel tail: duplicate the last plane, never stored
+      const float* plane = cbase + (int64_t)cc * L.stride_c;
+      float* dst = buf + c * PS;
+#pragma unroll
+      for (int k = 0; k < kDmaMaxChunks; k++)
+        if (k < nch) dma_load_dword(plane + goff[k], dst + k * 64);
+    }
+  };
+  const int ctm = ct - 1, ctsh = ct == 32 ? 5 : (ct == 16 ? 4 : 3);
+  const int ch = lane & ctm, sub = lane >> ctsh, nb = 64 >> ctsh;   // lane -> (channel of the sub-tile, bin slot)
+  const int npass = ceil_div(nc, ct);
+  issue(0, buf0);
+  for (int i = 0; i < npass; i++) {
+    float* buf = (i & 1) ? buf1 : buf0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's DMA pieces (and slab stores) have landed
+    __syncthreads();                                            // ... everybody's: buf is readable, slab/other buffer free
+    if (i + 1 < npass) issue((i + 1) * ct, (i & 1) ? buf0 : buf1);
+    const float* plane = buf + ch * PS;
+    for (int bin0 = 0; bin0 < bins; bin0 += (kRoiAlignThreads / 64) * nb) {
+      const int bin = bin0 + wv * nb + sub;
+      if (bin < bins) {
+        const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
+        float acc = 0.f;
+        for (int iy = 0; iy < gh; iy++) {
+          const LdsAxis y = yl[ph * gh + iy];
+          for (int ix = 0; ix < gw; ix++) {
+            const LdsAxis x = xl[pw * gw + ix];
+            const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;   // roi_align_cpu_loop.cpp:95
+            acc += w1 * plane[y.lo + x.lo] + w2 * plane[y.lo + x.hi] + w3 * plane[y.hi + x.lo] +
+                   w4 * plane[y.hi + x.hi];                                                // :208-211
+          }
+        }
+        slab[ch * bins + bin] = inv_count != 0.f ? acc * inv_count : fdiv(acc, count);     // :216
+      }
+    }
+    __syncthreads();
+    const int cs = i * ct;
+    const int nvalid = min(ct, nc - cs);
+    TOut* og = out + (size_t)cs * bins;
+    const int n_out = nvalid * bins;
+    if (sizeof(TOut) == 4 && ((reinterpret_cast<uintptr_t>(og) & 15) == 0)) {
+      const int n4 = n_out >> 2;
+      for (int j = tid; j < n4; j += kRoiAlignThreads) reinterpret_cast<float4*>(og)[j] = reinterpret_cast<const float4*>(slab)[j];
+      for (int j = (n4 << 2) + tid; j < n_out; j += kRoiAlignThreads) og[j] = from_f32<TOut>(slab[j]);
+    } else {
+      for (int j = tid; j < n_out; j += kRoiAlignThreads) og[j] = from_f32<TOut>(slab[j]);
+    }
+  }
+}
+
+template <typename TOut>
+static int launch_dma(const RoiAlignParams& p, hipStream_t stream, int lds_b) {
+  if (p.n_rois == 0) return DTC_OK;
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_dma<TOut>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
+    raised = true;
+  }
+  const int nct = ceil_div(p.channels, p.ch_block);
+  hipLaunchKernelGGL((roi_align_fwd_dma<TOut>), dim3((unsigned)p.n_rois * nct), dim3(kRoiAlignThreads), lds_b, stream, p,
+                     lds_b / 4);
+  DTC_CHECK_LAUNCH();
+  return DTC_OK;
+}
+
 static int lds_bytes() {
   static int v = 0;
   if (!v) { const char* e = getenv("DTC_ROIALIGN_LDS_KB"); v = (e ? atoi(e) : 52) * 1024; if (v < 16 * 1024 || v > 160 * 1024) v = 52 * 1024; }
@@ -691,6 +890,15 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
     if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return dtc::launch_nhwc<__half, float>(p, s);
     if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return dtc::launch_nhwc<__half, __half>(p, s);
     if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return dtc::launch_nhwc<float, __half>(p, s);
+    return DTC_EUNSUPPORTED;
+  }
+  // LDS-DMA variant: bit-exact and tested, but SLOWER on MI355X than the register-prefetch kernel (8000 RoIs: 0.84 vs
+  // 0.71 ms): with 4 bytes per lane a `global_load_lds_dword` moves only 256 B per instruction and a workgroup needs ~1200 of
+  // them per RoI -- the DMA issue rate, not bytes in flight, becomes the limit.  Kept behind DTC_ROIALIGN_DMA=1 for A/B runs.
+  if (lds_ok && in_dtype == DTC_F32 && !all_nhwc && getenv("DTC_ROIALIGN_DMA") != nullptr) {
+    int lds_b = dtc::lds_bytes();
+    if (out_dtype == DTC_F32) return dtc::launch_dma<float>(p, s, lds_b);
+    if (out_dtype == DTC_F16) return dtc::launch_dma<__half>(p, s, lds_b);
     return DTC_EUNSUPPORTED;
   }
   if (lds_ok) {
