@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--channels-last", action="store_true", help="NHWC feature maps (same logical shape)")
     ap.add_argument("--fp16", action="store_true", help="fp16 feature maps / pooled features (BASELINE cfg5 flavour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=4, help="images of the same workload timed on the CPU oracle")
+    ap.add_argument("--cpu-images", type=int, default=8, help="images of the same workload timed on the CPU oracle")
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--split", type=int, default=1, help="sub-batches run on separate HIP streams inside one hipGraph")
     return ap.parse_args()
