@@ -134,3 +134,46 @@ def test_linearity_full_size(hip):
     b = hip.roi_align_forward([f * 4.0 for f in feats], synth.FPN_ROI_SCALES, rois, 7, 7, 2, roi_levels=lv)
     assert torch.equal(a * 4.0, b)
     assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+
+
+@pytest.mark.parametrize("C", [1, 3, 5, 33, 65, 130])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_ragged_channel_counts_and_shapes(hip, oracle, C, layout):
+    """Channel tails (C not a multiple of 4 / 8 / 64), odd pooled sizes, sampling ratios 1..3 and adaptive, tiny maps, both
+    layouts: every kernel variant (LDS-staged, channels_last direct, general) against the oracle, bit-exact."""
+    rs = synth.rng(1, 100 + C)
+    for (H, W, ph, pw, sr, scale) in [(20, 30, 7, 7, 2, 1 / 16.), (9, 5, 1, 1, 1, 0.5), (13, 21, 2, 3, 3, 1 / 64.),
+                                      (25, 42, 14, 14, 2, 1 / 32.), (50, 84, 7, 7, 0, 1 / 16.), (1, 1, 3, 3, 2, 0.25)]:
+        feat = rs.standard_normal((2, C, H, W)).astype(np.float32)
+        im_w, im_h = W / scale, H / scale
+        rois = synth.make_rois(rs, 40, im_h=int(im_h) + 1, im_w=int(im_w) + 1, min_side=2, max_side=max(im_w, im_h) * 1.2)
+        rois[::7] += 30.0                                   # some rois partly / fully outside the map
+        rois5 = np.hstack([rs.randint(0, 2, (40, 1)).astype(np.float32), rois]).astype(np.float32)
+        ref = oracle.roi_align_forward(feat, rois5, ph, pw, scale, sr)
+        f = cu(feat)
+        if layout == "nhwc":
+            f = f.contiguous(memory_format=torch.channels_last)
+        out = hip.roi_align_forward(f, scale, cu(rois5), ph, pw, sr).cpu().numpy()
+        assert np.array_equal(out, ref), (C, layout, H, W, ph, pw, sr)
+
+
+def test_ordered_and_packed_entry_points(hip, oracle):
+    feats, rois5, lv, ref = _fpn_case(oracle, 200, 16, 7, 2, 4242, batch=2)
+    tf = [cu(f) for f in feats]
+    order = torch.from_numpy(np.random.RandomState(0).permutation(200).astype(np.int32)).cuda()
+    out = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, cu(rois5), 7, 7, 2, roi_levels=cu(lv), roi_order=order)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    # packed descriptors (batch, x1, y1, x2, y2, level, output row, 0) in visiting order, incl. a padding row (level -1)
+    o = order.cpu().numpy()
+    desc = np.zeros((201, 8), np.float32)
+    desc[:200, :5] = rois5[o]
+    desc[:200, 5] = lv[o]
+    desc[:200, 6] = o
+    desc[200] = [0, 0, 0, 10, 10, -1, 200, 0]
+    outp = torch.full((201, 16, 7, 7), 7.0, device="cuda")
+    lvs, ch, dt = hip.make_levels(tf, synth.FPN_ROI_SCALES)
+    rc = hip.lib().dtc_roi_align_forward_packed(lvs, 4, ch, 0, cu(desc).data_ptr(), 201, 7, 7, 2, outp.data_ptr(), 0,
+                                                hip.stream_ptr())
+    assert rc == 0
+    res = outp.cpu().numpy()
+    assert np.array_equal(res[:200], ref) and not res[200].any()
