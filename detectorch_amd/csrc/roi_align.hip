@@ -162,7 +162,7 @@ struct StagerNCHW {
   float v[G][K];
   uint32_t voff[K];   // byte offset of (pixel k, channel cl) from the sub-tile base plane
   int32_t lbase[K];   // LDS word index of pixel k + cl
-  int cl;
+  int cl, nk;         // nk = chunks that contain window pixels (uniform): chunks beyond are neither loaded nor written
   int64_t stride_c;
   __device__ __forceinline__ void init(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int npix, int cts) {
     const int tid = threadIdx.x;
@@ -170,6 +170,7 @@ struct StagerNCHW {
     cl = (tid >> 4) & 3;
     stride_c = L.stride_c;
     const int ctp = cts + kLdsPad;
+    nk = ceil_div(ceil_div(npix, 16), kRoiAlignThreads / 64);
     const int q64 = 64 / ww, r64 = 64 - q64 * ww;       // uniform
     int pix = wv * 16 + pl;
     int py = pix / ww, px = pix - py * ww;
@@ -194,7 +195,8 @@ struct StagerNCHW {
         if (4 * g < cts) {
           const char* gb = cb + (int64_t)(4 * g) * stride_c * (int64_t)sizeof(TIn);   // uniform
 #pragma unroll
-          for (int k = 0; k < K; k++) v[g][k] = to_f32<TIn>(*reinterpret_cast<const TIn*>(gb + voff[k]));
+          for (int k = 0; k < K; k++)
+            if (k < nk) v[g][k] = to_f32<TIn>(*reinterpret_cast<const TIn*>(gb + voff[k]));
         }
       }
     } else {  // channel tail (C % 64 != 0): clamp the plane index, results of the clamped planes are never stored
@@ -204,7 +206,8 @@ struct StagerNCHW {
           const int c = min(4 * g + cl, nvalid - 1) - cl;
           const char* gb = cb + (int64_t)c * stride_c * (int64_t)sizeof(TIn);
 #pragma unroll
-          for (int k = 0; k < K; k++) v[g][k] = to_f32<TIn>(*reinterpret_cast<const TIn*>(gb + voff[k]));
+          for (int k = 0; k < K; k++)
+            if (k < nk) v[g][k] = to_f32<TIn>(*reinterpret_cast<const TIn*>(gb + voff[k]));
         }
       }
     }
@@ -214,7 +217,8 @@ struct StagerNCHW {
     for (int g = 0; g < G; g++) {
       if (4 * g < cts) {
 #pragma unroll
-        for (int k = 0; k < K; k++) win[lbase[k] + 4 * g] = v[g][k];
+        for (int k = 0; k < K; k++)
+          if (k < nk) win[lbase[k] + 4 * g] = v[g][k];
       }
     }
   }
@@ -228,7 +232,7 @@ struct StagerNHWC {
   float4 v[U];
   uint32_t voff[U];
   int32_t loff[U];
-  int cq;
+  int cq, nu;         // nu = pixel rounds that contain window pixels (uniform)
   bool vec_ok;
   static __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
   static __device__ __forceinline__ float4 load4(const __half* p) {
@@ -242,6 +246,7 @@ struct StagerNHWC {
     vec_ok = ((L.stride_h | L.stride_w | L.stride_n) & 3) == 0 && (reinterpret_cast<uintptr_t>(L.data) & 15) == 0;
     const int pslot = threadIdx.x / quads, nslot = kRoiAlignThreads / quads;
     const int ctp = cts + kLdsPad;
+    nu = ceil_div(npix, nslot);
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int pix = pslot + u * nslot;
@@ -256,6 +261,7 @@ struct StagerNHWC {
     const bool full = (nvalid == cts);
 #pragma unroll
     for (int u = 0; u < U; u++) {
+      if (u >= nu) continue;
       const TIn* src = reinterpret_cast<const TIn*>(cb + voff[u]);
       if (full && vec_ok) {
         v[u] = load4(src);       // one 16-byte (fp32) / 8-byte (fp16) load: cts/4 lanes cover a pixel's tile contiguously
@@ -272,7 +278,8 @@ struct StagerNHWC {
   }
   __device__ __forceinline__ void commit(float* win, int cts) {
 #pragma unroll
-    for (int u = 0; u < U; u++) *reinterpret_cast<float4*>(win + loff[u]) = v[u];
+    for (int u = 0; u < U; u++)
+      if (u < nu) *reinterpret_cast<float4*>(win + loff[u]) = v[u];
   }
 };
 
