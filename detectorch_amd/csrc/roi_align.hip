@@ -54,6 +54,46 @@ __device__ __forceinline__ AxisEntry make_axis(float start, float bin, int p, in
   return e;
 }
 
+// What every workgroup derives from its RoI before touching features (roi_align_cpu_loop.cpp:143-173): which RoI / level /
+// image, the scaled box (NO rounding, :150-153), bin sizes, sampling grid and the divisor.
+struct RoiHead {
+  int r, lvl, b;              // output row, level index (< 0: padding row), image index
+  float sw, sh, rw, rh;       // scaled start (w, h) and size, size clamped to >= 1 (:160-161)
+  float bin_h, bin_w;         // :162-163
+  int gh, gw;                 // sampling grid (:166-170): fixed, or adaptive ceil(roi / pooled)
+  float count, inv_count;     // :173 ; inv_count != 0 when count is a power of two (x * inv_count == x / count exactly)
+};
+
+__device__ __forceinline__ RoiHead load_roi_head(const RoiAlignParams& p, int ri) {
+  RoiHead h;
+  float x1, y1, x2, y2;
+  h.b = 0;
+  if (p.roi_desc) {   // one packed 32-byte descriptor in visiting order
+    const float4 d0 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2];
+    const float4 d1 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2 + 1];
+    h.b = (int)d0.x; x1 = d0.y; y1 = d0.z; x2 = d0.w; y2 = d1.x; h.lvl = (int)d1.y; h.r = (int)d1.z;
+  } else {
+    h.r = p.roi_order ? p.roi_order[ri] : ri;
+    h.lvl = p.roi_levels ? p.roi_levels[h.r] : 0;
+    const float* roi = p.rois + (size_t)h.r * p.roi_cols;
+    if (p.roi_cols == 5) { h.b = (int)roi[0]; roi++; }          // :143-147
+    x1 = roi[0]; y1 = roi[1]; x2 = roi[2]; y2 = roi[3];
+  }
+  h.sw = h.sh = 0.f; h.rw = h.rh = 1.f; h.bin_h = h.bin_w = 1.f; h.gh = h.gw = 1; h.count = 1.f; h.inv_count = 1.f;
+  if (h.lvl < 0 || h.lvl >= p.n_levels) return h;
+  const float s = p.lv[h.lvl].spatial_scale;
+  h.sw = x1 * s; h.sh = y1 * s;
+  const float ew = x2 * s, eh = y2 * s;
+  h.rw = fmaxf(ew - h.sw, 1.f); h.rh = fmaxf(eh - h.sh, 1.f);
+  h.bin_h = fdiv(h.rh, (float)p.pooled_h); h.bin_w = fdiv(h.rw, (float)p.pooled_w);
+  h.gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(h.rh, (float)p.pooled_h));
+  h.gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(h.rw, (float)p.pooled_w));
+  const int gg = h.gh * h.gw;
+  h.count = (float)gg;
+  h.inv_count = ((gg & (gg - 1)) == 0) ? fdiv(1.f, h.count) : 0.f;
+  return h;
+}
+
 constexpr int kRoiAlignThreads = 256;
 constexpr int kMaxTableEntries = 2048;  // PH*gh + PW*gw ; larger (adaptive sampling on a huge RoI) -> on-the-fly path
 
@@ -64,9 +104,9 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_general(RoiAli
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   AxisEntry* ytab = reinterpret_cast<AxisEntry*>(smem);
 
-  const int r = p.roi_order ? p.roi_order[blockIdx.x] : blockIdx.x;
   const int c0 = blockIdx.y * p.ch_tile;
-  const int lvl = p.roi_levels ? p.roi_levels[r] : 0;
+  const RoiHead hd = load_roi_head(p, blockIdx.x);
+  const int r = hd.r, lvl = hd.lvl, b = hd.b;
   if (lvl < 0 || lvl >= p.n_levels) {  // padding row of a fixed-shape batch (fpn.hip emits level -1): defined output
     const int bins0 = p.pooled_h * p.pooled_w;
     const int nc0 = min(p.ch_tile, p.channels - c0);
@@ -75,16 +115,8 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_general(RoiAli
     return;
   }
   const dtc_feat_level L = p.lv[lvl];
-  const float* roi = p.rois + (size_t)r * p.roi_cols;
-  int b = 0;
-  if (p.roi_cols == 5) { b = (int)roi[0]; roi++; }              // roi_align_cpu_loop.cpp:143-147
-  const float s = L.spatial_scale;
-  const float sw = roi[0] * s, sh = roi[1] * s, ew = roi[2] * s, eh = roi[3] * s;  // :150-153 no rounding
-  const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);                // :160-161
-  const float bin_h = fdiv(rh, (float)p.pooled_h), bin_w = fdiv(rw, (float)p.pooled_w);  // :162-163
-  const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(rh, (float)p.pooled_h));  // :166-170
-  const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(rw, (float)p.pooled_w));
-  const float count = (float)(gh * gw);                                          // :173
+  const float sw = hd.sw, sh = hd.sh, bin_h = hd.bin_h, bin_w = hd.bin_w, count = hd.count;
+  const int gh = hd.gh, gw = hd.gw;
   const int ny = p.pooled_h * gh, nx = p.pooled_w * gw;
   const bool use_tab = (ny + nx) <= kMaxTableEntries;
   AxisEntry* xtab = ytab + ny;
@@ -294,19 +326,19 @@ struct LdsGeom {
 };
 
 template <typename TIn, typename TOut, typename Stager>
-__device__ __forceinline__ void run_passes(Stager& st, const LdsGeom& G, const TIn* fbase0, int64_t stride_c, TOut* out, int dbg) {
+__device__ __forceinline__ void run_passes(Stager& st, const LdsGeom& G, const TIn* fbase0, int64_t stride_c, TOut* out) {
   const int tid = threadIdx.x;
   const int quads = G.cts >> 2;
   const int cq = tid % quads, slot = tid / quads, nslot = kRoiAlignThreads / quads;
   const float* wq = G.win + cq * 4;
-  if (!(dbg & 1)) st.issue(fbase0, G.cts, min(G.cts, G.nc));
+  st.issue(fbase0, G.cts, min(G.cts, G.nc));
   for (int cs = 0; cs < G.nc; cs += G.cts) {
     const int nvalid = min(G.cts, G.nc - cs);
-    if (!(dbg & 8)) st.commit(G.win, G.cts);
+    st.commit(G.win, G.cts);
     __syncthreads();
-    if (cs + G.cts < G.nc && !(dbg & 1))  // prefetch the next channel sub-tile into registers; lands while this one is computed
+    if (cs + G.cts < G.nc)  // prefetch the next channel sub-tile into registers; lands while this one is computed
       st.issue(fbase0 + (int64_t)(cs + G.cts) * stride_c, G.cts, min(G.cts, G.nc - cs - G.cts));
-    for (int bin = slot; bin < ((dbg & 2) ? 0 : G.bins); bin += nslot) {
+    for (int bin = slot; bin < G.bins; bin += nslot) {
       const int ph = bin / G.pooled_w, pw = bin - ph * G.pooled_w;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       // reference order: for iy { for ix { acc += ... } }   (roi_align_cpu_loop.cpp:203-214)
@@ -335,7 +367,7 @@ __device__ __forceinline__ void run_passes(Stager& st, const LdsGeom& G, const T
     __syncthreads();
     // coalesced store of the [nvalid][bins] slab
     TOut* og = out + (size_t)cs * G.bins;
-    const int n_out = (dbg & 4) ? 0 : nvalid * G.bins;
+    const int n_out = nvalid * G.bins;
     if (sizeof(TOut) == 4 && ((reinterpret_cast<uintptr_t>(og) & 15) == 0)) {
       const int n4 = n_out >> 2;
       for (int i = tid; i < n4; i += kRoiAlignThreads)
@@ -352,7 +384,7 @@ __device__ __forceinline__ void run_passes(Stager& st, const LdsGeom& G, const T
 #define DTC_RA_WAVES 3
 #endif
 template <typename TIn, typename TOut>
-__global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_lds(RoiAlignParams p, int lds_floats, int dbg) {
+__global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_lds(RoiAlignParams p, int lds_floats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* lds = reinterpret_cast<float*>(smem);
   AxisEntry* ytab = reinterpret_cast<AxisEntry*>(smem);
@@ -363,33 +395,16 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   const int nc = min(p.ch_block, p.channels - c0);
   const int bins = p.pooled_h * p.pooled_w;
   const int tid = threadIdx.x;
-  int r, lvl, b = 0;
-  float rx1, ry1, rx2, ry2;
-  if (p.roi_desc) {
-    const float4 d0 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2];
-    const float4 d1 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2 + 1];
-    b = (int)d0.x; rx1 = d0.y; ry1 = d0.z; rx2 = d0.w; ry2 = d1.x; lvl = (int)d1.y; r = (int)d1.z;
-  } else {
-    r = p.roi_order ? p.roi_order[ri] : ri;
-    lvl = p.roi_levels ? p.roi_levels[r] : 0;
-    const float* roi = p.rois + (size_t)r * p.roi_cols;
-    if (p.roi_cols == 5) { b = (int)roi[0]; roi++; }
-    rx1 = roi[0]; ry1 = roi[1]; rx2 = roi[2]; ry2 = roi[3];
-  }
+  const RoiHead hd = load_roi_head(p, ri);
+  const int r = hd.r, lvl = hd.lvl, b = hd.b;
   TOut* out = reinterpret_cast<TOut*>(p.out) + ((size_t)r * p.channels + c0) * bins;
   if (lvl < 0 || lvl >= p.n_levels) {  // padding row (fpn.hip emits level -1): defined output
     for (int o = tid; o < nc * bins; o += kRoiAlignThreads) out[o] = from_f32<TOut>(0.f);
     return;
   }
   const dtc_feat_level L = p.lv[lvl];
-  const float s = L.spatial_scale;
-  const float sw = rx1 * s, sh = ry1 * s, ew = rx2 * s, eh = ry2 * s;
-  const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
-  const float bin_h = fdiv(rh, (float)p.pooled_h), bin_w = fdiv(rw, (float)p.pooled_w);
-  // sampling grid: fixed, or adaptive ceil(roi / pooled) per axis (roi_align_cpu_loop.cpp:166-170)
-  const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(rh, (float)p.pooled_h));
-  const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(rw, (float)p.pooled_w));
-  const float count = (float)(gh * gw);
+  const float sw = hd.sw, sh = hd.sh, bin_h = hd.bin_h, bin_w = hd.bin_w, count = hd.count;
+  const int gh = hd.gh, gw = hd.gw;
   const int ny = p.pooled_h * gh, nx = p.pooled_w * gw;
   const bool tab_ok = (ny + nx) * 4 <= kLdsTableFloats;
   AxisEntry* xtab = ytab + ny;
@@ -466,17 +481,16 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   G.slab = lds + kLdsTableFloats;                 // [cts][bins] output staging
   G.win = G.slab + cts * bins;                    // [npix + 1][cts + 4]  (cts*bins is a multiple of 4 -> 16 B aligned)
   G.cts = cts; G.bins = bins; G.gh = gh; G.gw = gw; G.pooled_w = p.pooled_w; G.nc = nc; G.count = count;
-  const int gg = gh * gw;
-  G.inv_count = ((gg & (gg - 1)) == 0) ? fdiv(1.f, count) : 0.f;
+  G.inv_count = hd.inv_count;
   const TIn* cbase = fbase + (int64_t)c0 * L.stride_c;
   if (L.stride_c == 1) {
     StagerNHWC<TIn> st; st.init(L, y0, x0, ww, wh, npix, cts);
-    run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out, dbg);
+    run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out);
   } else {
     const int nk = ceil_div(ceil_div(npix, 16), kRoiAlignThreads / 64);
-    if (nk <= 4) { StagerNCHW<TIn, 4, 8> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out, dbg); }
-    else if (nk <= 8) { StagerNCHW<TIn, 8, 4> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out, dbg); }
-    else { StagerNCHW<TIn, 16, 2> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out, dbg); }
+    if (nk <= 4) { StagerNCHW<TIn, 4, 8> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
+    else if (nk <= 8) { StagerNCHW<TIn, 8, 4> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
+    else { StagerNCHW<TIn, 16, 2> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
   }
 }
 
@@ -514,34 +528,16 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
   const int nc = min(64, p.channels - c0);
   const int bins = p.pooled_h * p.pooled_w;
   const int tid = threadIdx.x;
-  int r, lvl, b = 0;
-  float rx1, ry1, rx2, ry2;
-  if (p.roi_desc) {
-    const float4 d0 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2];
-    const float4 d1 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2 + 1];
-    b = (int)d0.x; rx1 = d0.y; ry1 = d0.z; rx2 = d0.w; ry2 = d1.x; lvl = (int)d1.y; r = (int)d1.z;
-  } else {
-    r = p.roi_order ? p.roi_order[ri] : ri;
-    lvl = p.roi_levels ? p.roi_levels[r] : 0;
-    const float* roi = p.rois + (size_t)r * p.roi_cols;
-    if (p.roi_cols == 5) { b = (int)roi[0]; roi++; }
-    rx1 = roi[0]; ry1 = roi[1]; rx2 = roi[2]; ry2 = roi[3];
-  }
+  const RoiHead hd = load_roi_head(p, ri);
+  const int r = hd.r, lvl = hd.lvl, b = hd.b;
   TOut* out = reinterpret_cast<TOut*>(p.out) + ((size_t)r * p.channels + c0) * bins;
   if (lvl < 0 || lvl >= p.n_levels) {
     for (int o = tid; o < nc * bins; o += kRoiAlignThreads) out[o] = from_f32<TOut>(0.f);
     return;
   }
   const dtc_feat_level L = p.lv[lvl];
-  const float s = L.spatial_scale;
-  const float sw = rx1 * s, sh = ry1 * s, ew = rx2 * s, eh = ry2 * s;
-  const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
-  const float bin_h = fdiv(rh, (float)p.pooled_h), bin_w = fdiv(rw, (float)p.pooled_w);
-  const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(rh, (float)p.pooled_h));
-  const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(rw, (float)p.pooled_w));
-  const float count = (float)(gh * gw);
-  const int gg = gh * gw;
-  const float inv_count = ((gg & (gg - 1)) == 0) ? fdiv(1.f, count) : 0.f;
+  const float sw = hd.sw, sh = hd.sh, bin_h = hd.bin_h, bin_w = hd.bin_w, count = hd.count, inv_count = hd.inv_count;
+  const int gh = hd.gh, gw = hd.gw;
   const int ny = p.pooled_h * gh, nx = p.pooled_w * gw;
   const bool tab_ok = (ny + nx) * 4 <= kLdsTableFloats;
   AxisEntry* xtab = ytab + ny;
@@ -656,34 +652,16 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_dma(RoiAlignPa
   const int nc = min(p.ch_block, p.channels - c0);
   const int bins = p.pooled_h * p.pooled_w;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int r, lvl, b = 0;
-  float rx1, ry1, rx2, ry2;
-  if (p.roi_desc) {
-    const float4 d0 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2];
-    const float4 d1 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2 + 1];
-    b = (int)d0.x; rx1 = d0.y; ry1 = d0.z; rx2 = d0.w; ry2 = d1.x; lvl = (int)d1.y; r = (int)d1.z;
-  } else {
-    r = p.roi_order ? p.roi_order[ri] : ri;
-    lvl = p.roi_levels ? p.roi_levels[r] : 0;
-    const float* roi = p.rois + (size_t)r * p.roi_cols;
-    if (p.roi_cols == 5) { b = (int)roi[0]; roi++; }
-    rx1 = roi[0]; ry1 = roi[1]; rx2 = roi[2]; ry2 = roi[3];
-  }
+  const RoiHead hd = load_roi_head(p, ri);
+  const int r = hd.r, lvl = hd.lvl, b = hd.b;
   TOut* out = reinterpret_cast<TOut*>(p.out) + ((size_t)r * p.channels + c0) * bins;
   if (lvl < 0 || lvl >= p.n_levels) {
     for (int o = tid; o < nc * bins; o += kRoiAlignThreads) out[o] = from_f32<TOut>(0.f);
     return;
   }
   const dtc_feat_level L = p.lv[lvl];
-  const float s = L.spatial_scale;
-  const float sw = rx1 * s, sh = ry1 * s, ew = rx2 * s, eh = ry2 * s;
-  const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
-  const float bin_h = fdiv(rh, (float)p.pooled_h), bin_w = fdiv(rw, (float)p.pooled_w);
-  const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(rh, (float)p.pooled_h));
-  const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(rw, (float)p.pooled_w));
-  const float count = (float)(gh * gw);
-  const int gg = gh * gw;
-  const float inv_count = ((gg & (gg - 1)) == 0) ? fdiv(1.f, count) : 0.f;
+  const float sw = hd.sw, sh = hd.sh, bin_h = hd.bin_h, bin_w = hd.bin_w, count = hd.count, inv_count = hd.inv_count;
+  const int gh = hd.gh, gw = hd.gw;
   const int ny = p.pooled_h * gh, nx = p.pooled_w * gw;
   const bool tab_ok = (ny + nx) * 4 <= kLdsTableFloats;
   AxisEntry* xtab = ytab + ny;
@@ -836,7 +814,7 @@ static int launch_lds(const RoiAlignParams& p, hipStream_t stream) {
   }
   const int nct = ceil_div(p.channels, p.ch_block);
   hipLaunchKernelGGL((roi_align_fwd_lds<TIn, TOut>), dim3((unsigned)p.n_rois * nct), dim3(kRoiAlignThreads), lds_bytes(),
-                     stream, p, lds_bytes() / 4, getenv("DTC_RA_DBG") ? atoi(getenv("DTC_RA_DBG")) : 0);
+                     stream, p, lds_bytes() / 4);
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }
@@ -885,7 +863,6 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   // per-output gather kernel (kept as the reference implementation of the arithmetic and for A/B measurements).
   const bool lds_ok = (sampling_ratio <= 0 || (pooled_h + pooled_w) * sampling_ratio * 4 <= dtc::kLdsTableFloats) &&
                       (long long)pooled_h * pooled_w * 8 <= 4096 && getenv("DTC_ROIALIGN_GENERAL") == nullptr;
-  if (roi_desc && !lds_ok) return DTC_EUNSUPPORTED;   // packed descriptors are an LDS-kernel feature
   bool all_nhwc = channels > 1;
   for (int i = 0; i < n_levels; i++) all_nhwc = all_nhwc && levels[i].stride_c == 1;
   // direct gather pays when a window pixel is re-used only a few times (7x7 bins x 2x2 samples over a ~300-pixel window:

@@ -73,7 +73,7 @@ int dtc_roi_align_forward_ordered(const dtc_feat_level* levels, int n_levels, in
 
 /* Same, driven by packed descriptors: roi_desc float32 [R,8] = (batch, x1, y1, x2, y2, level, output_row, 0), one row per
  * workgroup in visiting order (level < 0: padding row, its output row is zero-filled).  Saves the three dependent global
- * loads (order -> level -> roi) at the head of every workgroup.  sampling_ratio > 0 only. */
+ * loads (order -> level -> roi) at the head of every workgroup. */
 int dtc_roi_align_forward_packed(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,
                                  const float* roi_desc, int n_rois, int pooled_h, int pooled_w, int sampling_ratio, void* out,
                                  int out_dtype, dtc_stream_t stream);
