@@ -63,7 +63,8 @@ constexpr int kMaskWaves = 4;  // a workgroup = 4 wavefronts = 4 consecutive col
 __global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4* __restrict__ boxes,
                                                                    const int32_t* __restrict__ counts, int n_stride,
                                                                    int ncb_stride, float thresh,
-                                                                   uint64_t* __restrict__ mask) {
+                                                                   uint64_t* __restrict__ mask,
+                                                                   uint64_t* __restrict__ diag_t) {
   // grid = (GX, 1, n_seg): a workgroup walks the (row block, column-block group) tiles of ITS segment with stride GX.
   // The iteration space is derived from the segment's actual count, so the 600+ class segments of a detection batch
   // (mostly <= 64 candidates = one tile) cost one short workgroup each instead of a worst-case 16x4 tile grid whose
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4*
     const bool col_ok = col < n;
     const float4 cbox = col_ok ? B[col] : make_float4(0.f, 0.f, -1.f, -1.f);
     const float carea = box_area(cbox);
-    uint64_t myword = 0;
+    uint64_t myword = 0, mycol = 0;
 #pragma unroll 8
     for (int i = 0; i < 64; i++) {
       const float4 r = rbox_s[i];                                // uniform address: LDS broadcast
@@ -116,9 +117,11 @@ __global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4*
       const bool sup = col_ok && (col > rb * 64 + i) && ge;                    // :72 (_j > _i), :84
       const uint64_t word = __ballot(sup);
       if (lane == i) myword = word;
+      mycol |= (uint64_t)(sup ? 1 : 0) << i;             // column view of the same tile: rows that suppress MY column
     }
     const int row = rb * 64 + lane;
     if (row < n) mask[((size_t)s * n_stride + row) * ncb_stride + cb] = myword;
+    if (cb == rb && col_ok) diag_t[(size_t)s * n_stride + col] = mycol;   // transposed diagonal tile for the reduce
   }
 }
 
@@ -136,10 +139,11 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
 // block, cbl = lane & 15 one column word of a 16-word chunk.  All 16 loads of a (row block, chunk) are independent of the
 // resolve and are issued together (the diagonal chunk and diag words of the NEXT row block are prefetched while the current
 // one is resolved), so a row block costs one overlapped L2 round trip instead of two dependent ones.
-struct ReduceRegs { uint64_t w[16]; uint64_t diag; };
+struct ReduceRegs { uint64_t w[16]; uint64_t diag; };   // diag: TRANSPOSED diagonal tile word (suppressors of my column)
 
-__device__ __forceinline__ void reduce_load(ReduceRegs& R, const uint64_t* __restrict__ M, int ncb_stride, int n, int ncb,
-                                            int rb, int cbase, bool with_diag) {
+__device__ __forceinline__ void reduce_load(ReduceRegs& R, const uint64_t* __restrict__ M,
+                                            const uint64_t* __restrict__ DT, int ncb_stride, int n, int ncb, int rb,
+                                            int cbase, bool with_diag) {
   const int lane = threadIdx.x, rg = lane >> 4, cbl = lane & 15;
   const int c = cbase + cbl;
 #pragma unroll
@@ -149,11 +153,12 @@ __device__ __forceinline__ void reduce_load(ReduceRegs& R, const uint64_t* __res
   }
   if (with_diag) {
     const int row = rb * 64 + lane;
-    R.diag = row < n ? M[(size_t)row * ncb_stride + rb] : 0ull;
+    R.diag = row < n ? DT[row] : 0ull;
   }
 }
 
 __global__ __launch_bounds__(64) void nms_reduce_kernel(const uint64_t* __restrict__ mask,
+                                                        const uint64_t* __restrict__ diag_t,
                                                         const int32_t* __restrict__ counts, int n_stride,
                                                         int ncb_stride, int max_keep, int32_t* __restrict__ keep,
                                                         int keep_stride, int32_t* __restrict__ keep_count) {
@@ -162,27 +167,42 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const uint64_t* __restri
   const int n = counts ? min(counts[s], n_stride) : n_stride;
   const int ncb = (n + 63) >> 6;
   const uint64_t* M = mask + (size_t)s * n_stride * ncb_stride;
+  const uint64_t* DT = diag_t + (size_t)s * n_stride;
   int32_t* K = keep + (size_t)s * keep_stride;
   const int cap = max_keep > 0 ? min(max_keep, keep_stride) : keep_stride;
   for (int i = lane; i < 256; i += 64) removed[i] = 0;
   __syncthreads();
   int kept = 0;
   ReduceRegs cur, nxt;
-  if (ncb > 0) reduce_load(cur, M, ncb_stride, n, ncb, 0, 0, true);
+  if (ncb > 0) reduce_load(cur, M, DT, ncb_stride, n, ncb, 0, 0, true);
   for (int rb = 0; rb < ncb && kept < cap; rb++) {
     const int cbase0 = rb & ~15;
-    if (rb + 1 < ncb) reduce_load(nxt, M, ncb_stride, n, ncb, rb + 1, (rb + 1) & ~15, true);   // prefetch
+    if (rb + 1 < ncb) reduce_load(nxt, M, DT, ncb_stride, n, ncb, rb + 1, (rb + 1) & ~15, true);   // prefetch
     const int left = n - rb * 64;
     const uint64_t valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
     uint64_t cand = valid & ~removed[rb];
     cand = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cand >> 32)) << 32) |
            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cand);   // uniform by construction: keep it in SGPRs
-    uint64_t keepw = 0;
-    while (cand != 0 && kept < cap) {          // scalar loop over KEPT rows only
-      const int i = __builtin_ctzll(cand);
-      keepw |= 1ull << i;
-      kept++;
-      cand &= ~(readlane64(cur.diag, i) | (1ull << i));
+    // In-block greedy resolve as a fixed point: row i is kept iff it is a candidate and no KEPT earlier row of the block
+    // suppresses it.  F(K) = {i in cand : (suppressors(i) & K) == 0} is antitone and the greedy answer is its unique fixed
+    // point; iterating from K = cand fixes the i-th candidate after at most i steps (typically 2-4 wave-wide steps in all,
+    // instead of one dependent scalar step per kept row).  suppressors(i) is this lane's word of the transposed diagonal
+    // tile, which only has bits of rows < i.
+    uint64_t keepw = cand;
+    if (cand != 0) {
+      for (int it = 0; it < 64; it++) {
+        const bool k_i = ((cand >> lane) & 1ull) && ((cur.diag & keepw) == 0ull);
+        const uint64_t nk = __ballot(k_i);
+        if (nk == keepw) break;
+        keepw = nk;
+      }
+      const int room = cap - kept;               // keep[:max_keep]: only the first `room` survivors of this block count
+      if (__builtin_popcountll(keepw) > room) {
+        uint64_t t = keepw, kk = 0;
+        for (int q = 0; q < room; q++) { kk |= t & (~t + 1ull); t &= t - 1ull; }
+        keepw = kk;
+      }
+      kept += __builtin_popcountll(keepw);
     }
     if ((keepw >> lane) & 1ull) {
       const int before = __builtin_popcountll(keepw & ((1ull << lane) - 1ull));
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const uint64_t* __restri
     }
     if (rb + 1 < ncb && kept < cap) {
       for (int cbase = cbase0; cbase < ncb; cbase += 16) {
-        if (cbase != cbase0) reduce_load(cur, M, ncb_stride, n, ncb, rb, cbase, false);
+        if (cbase != cbase0) reduce_load(cur, M, DT, ncb_stride, n, ncb, rb, cbase, false);
         uint64_t acc = 0;
 #pragma unroll
         for (int k = 0; k < 16; k++)
@@ -232,7 +252,9 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 DTC_API size_t dtc_nms_sorted_workspace_bytes(int n_seg, int n_stride) {
   const size_t ncb = (size_t)(n_stride + 63) / 64;
-  return dtc::align_up((size_t)n_seg * n_stride * ncb * sizeof(uint64_t), 256);
+  // suppression matrix [n_seg][n_stride][ncb] + transposed diagonal tiles [n_seg][n_stride]
+  return dtc::align_up((size_t)n_seg * n_stride * ncb * sizeof(uint64_t), 256) +
+         dtc::align_up((size_t)n_seg * n_stride * sizeof(uint64_t), 256);
 }
 
 DTC_API int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg, int n_stride, float thresh,
@@ -247,6 +269,8 @@ DTC_API int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg,
   const int ncb = (n_stride + 63) / 64;
   if (ncb > 64 * 4) return DTC_EUNSUPPORTED;  // > 16384 boxes per segment
   uint64_t* mask = reinterpret_cast<uint64_t*>(workspace);
+  uint64_t* diag_t = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(workspace) +
+                                                 dtc::align_up((size_t)n_seg * n_stride * ((n_stride + 63) / 64) * sizeof(uint64_t), 256));
   // workgroups per segment: all tile groups when there are few segments (RPN: 40 x 64), a handful when there are many
   // (detections: 640 class segments, mostly one tile each)
   const int groups = ncb * ((ncb + dtc::kMaskWaves - 1) / dtc::kMaskWaves);
@@ -254,9 +278,9 @@ DTC_API int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg,
   if (gx < 1) gx = 1;
   if (gx > groups) gx = groups;
   hipLaunchKernelGGL(dtc::nms_mask_kernel, dim3(gx, 1, n_seg), dim3(64 * dtc::kMaskWaves), 0, s,
-                     reinterpret_cast<const float4*>(boxes), counts, n_stride, ncb, thresh, mask);
+                     reinterpret_cast<const float4*>(boxes), counts, n_stride, ncb, thresh, mask, diag_t);
   DTC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dtc::nms_reduce_kernel, dim3(n_seg), dim3(64), 0, s, mask, counts, n_stride, ncb, max_keep, keep,
+  hipLaunchKernelGGL(dtc::nms_reduce_kernel, dim3(n_seg), dim3(64), 0, s, mask, diag_t, counts, n_stride, ncb, max_keep, keep,
                      keep_stride, keep_count);
   DTC_CHECK_LAUNCH();
   return DTC_OK;
