@@ -560,6 +560,32 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
     for (int bin = slot; bin < bins; bin += kRoiAlignThreads / 16) {
       const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      if (vec && tab_ok && gh == 2 && gw == 2) {
+        // 2x2 sampling grid: all 16 taps (four 16-byte loads per sample) are issued before the first one is consumed, so a
+        // bin costs ONE L2 round trip instead of four dependent ones
+        const AxisEntry x0e = xtab[pw * 2], x1e = xtab[pw * 2 + 1];
+        const AxisEntry y0e = ytab[ph * 2], y1e = ytab[ph * 2 + 1];
+        float4 t[16];
+        t[0] = Vec4Load<TIn>::ld(base + y0e.lo + x0e.lo); t[1] = Vec4Load<TIn>::ld(base + y0e.lo + x0e.hi);
+        t[2] = Vec4Load<TIn>::ld(base + y0e.hi + x0e.lo); t[3] = Vec4Load<TIn>::ld(base + y0e.hi + x0e.hi);
+        t[4] = Vec4Load<TIn>::ld(base + y0e.lo + x1e.lo); t[5] = Vec4Load<TIn>::ld(base + y0e.lo + x1e.hi);
+        t[6] = Vec4Load<TIn>::ld(base + y0e.hi + x1e.lo); t[7] = Vec4Load<TIn>::ld(base + y0e.hi + x1e.hi);
+        t[8] = Vec4Load<TIn>::ld(base + y1e.lo + x0e.lo); t[9] = Vec4Load<TIn>::ld(base + y1e.lo + x0e.hi);
+        t[10] = Vec4Load<TIn>::ld(base + y1e.hi + x0e.lo); t[11] = Vec4Load<TIn>::ld(base + y1e.hi + x0e.hi);
+        t[12] = Vec4Load<TIn>::ld(base + y1e.lo + x1e.lo); t[13] = Vec4Load<TIn>::ld(base + y1e.lo + x1e.hi);
+        t[14] = Vec4Load<TIn>::ld(base + y1e.hi + x1e.lo); t[15] = Vec4Load<TIn>::ld(base + y1e.hi + x1e.hi);
+#pragma unroll
+        for (int sidx = 0; sidx < 4; sidx++) {   // (iy, ix) = (0,0) (0,1) (1,0) (1,1): the reference's accumulation order
+          const AxisEntry& y = (sidx < 2) ? y0e : y1e;
+          const AxisEntry& x = (sidx & 1) ? x1e : x0e;
+          const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;
+          const float4 v1 = t[sidx * 4], v2 = t[sidx * 4 + 1], v3 = t[sidx * 4 + 2], v4 = t[sidx * 4 + 3];
+          a0 += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+          a1 += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+          a2 += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+          a3 += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+        }
+      } else {
       for (int iy = 0; iy < gh; iy++) {
         const AxisEntry y = tab_ok ? ytab[ph * gh + iy] : [&] { AxisEntry e = make_axis(sh, bin_h, ph, iy, gh, L.height); e.lo *= (int)L.stride_h; e.hi *= (int)L.stride_h; return e; }();
         for (int ix = 0; ix < gw; ix++) {
@@ -583,6 +609,7 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
           a2 += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
           a3 += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
         }
+      }
       }
       float* so = slab + (4 * q) * bins + bin;
       if (inv_count != 0.f) { so[0] = a0 * inv_count; so[bins] = a1 * inv_count; so[2 * bins] = a2 * inv_count; so[3 * bins] = a3 * inv_count; }
