@@ -643,6 +643,310 @@ static int launch_nhwc(const RoiAlignParams& p, hipStream_t stream) {
   return DTC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised kernel (NCHW features, the reference's layout).
+//
+// In roi_align_fwd_lds every wave both stages and computes, so the ~32 prefetch registers of the staging are live across
+// the compute phase (the 2x2 sample loop cannot be unrolled without spilling: no ILP on the LDS reads) and the gather
+// queue drains while the waves compute.  Here a 512-thread workgroup is split by ROLE:
+//   waves 0-3  LOADERS   only move data: global -> registers (two sub-tiles ahead) -> LDS window (pixel-major, [pix][cts+4])
+//   waves 4-7  COMPUTERS only pool: compute wave w owns channel quad w of the sub-tile for ALL bins (lane <-> bin), with
+//              the 2x2 sampling grid fully unrolled (16 ds_read_b128 in flight), transposes its [4][bins] results through a
+//              private LDS slab (wave-level ordering only) and stores them as one contiguous run.
+// Two LDS windows: loaders fill window (i+1)%2 while computers read window i%2; ONE workgroup barrier per sub-tile hands
+// a window over (both roles execute the same number of barriers, so there is nothing to deadlock on).  When two windows do
+// not fit, one window and two barriers per sub-tile are used.  Same arithmetic, same order: bit-identical output.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef DTC_WS_SETS
+#define DTC_WS_SETS 1
+#endif
+constexpr int kWsThreads = 512;
+constexpr int kWsLoaders = 256;
+
+template <typename TIn, int K, int G>
+struct WsLoader {
+  float v[2][G][K];   // two register sets = two sub-tiles in flight
+  uint32_t voff[K];
+  int32_t lbase[K];
+  int cl, nk;
+  int64_t stride_c;
+  __device__ __forceinline__ void init(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int npix, int cts) {
+    const int tid = threadIdx.x;                 // loaders are threads [0, 256)
+    const int pl = tid & 15, wv = tid >> 6;
+    cl = (tid >> 4) & 3;
+    stride_c = L.stride_c;
+    const int ctp = cts + kLdsPad;
+    nk = ceil_div(ceil_div(npix, 16), kWsLoaders / 64);
+    const int q64 = 64 / ww, r64 = 64 - q64 * ww;
+    int pix = wv * 16 + pl;
+    int py = pix / ww, px = pix - py * ww;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const bool ok = pix < npix;
+      const int ly = ok ? py : wh - 1, lx = ok ? px : ww - 1;
+      const int lp = ok ? pix : npix;                              // lanes past the window write the dummy pixel slot
+      voff[k] = (uint32_t)(((int64_t)(y0 + ly) * L.stride_h + (int64_t)(x0 + lx) * L.stride_w + (int64_t)cl * L.stride_c) *
+                           (int64_t)sizeof(TIn));
+      lbase[k] = lp * ctp + cl;
+      pix += 64; px += r64; py += q64;
+      if (px >= ww) { px -= ww; py++; }
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void issue(const TIn* cbase, int cts, int nvalid) {
+    const char* cb = reinterpret_cast<const char*>(cbase);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      if (4 * g < cts) {
+        const int c = min(4 * g + cl, nvalid - 1) - cl;          // channel tail: clamp the plane, never stored
+        const char* gb = cb + (int64_t)c * stride_c * (int64_t)sizeof(TIn);
+#pragma unroll
+        for (int k = 0; k < K; k++)
+          if (k < nk) v[S][g][k] = to_f32<TIn>(*reinterpret_cast<const TIn*>(gb + voff[k]));
+      }
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void commit(float* win, int cts) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      if (4 * g < cts) {
+#pragma unroll
+        for (int k = 0; k < K; k++)
+          if (k < nk) win[lbase[k] + 4 * g] = v[S][g][k];
+      }
+    }
+  }
+};
+
+struct WsGeom {
+  const LdsAxis* ytab; const LdsAxis* xtab;
+  float* win0; float* win1;      // win1 == win0 in single-window mode
+  float* slabs;                  // 4 private slabs of [4][bins]
+  int cts, bins, gh, gw, pooled_w, nc, nbuf;
+  float count, inv_count;
+};
+
+template <typename TIn, typename Loader>
+__device__ __forceinline__ void ws_loader_role(Loader& ld, const WsGeom& G, const TIn* cbase, int64_t stride_c) {
+  const int npass = ceil_div(G.nc, G.cts);
+  ld.template issue<0>(cbase, G.cts, min(G.cts, G.nc));
+#if DTC_WS_SETS == 1
+  for (int i = 0; i < npass; i++) {
+    ld.template commit<0>((i & 1) ? G.win1 : G.win0, G.cts);
+    if (i + 1 < npass) ld.template issue<0>(cbase + (int64_t)(i + 1) * G.cts * stride_c, G.cts, min(G.cts, G.nc - (i + 1) * G.cts));
+    __syncthreads();
+    if (G.nbuf == 1) __syncthreads();
+  }
+  return;
+#endif
+  if (npass > 1) ld.template issue<1>(cbase + (int64_t)G.cts * stride_c, G.cts, min(G.cts, G.nc - G.cts));
+  for (int i = 0; i < npass; i += 2) {
+    // even sub-tile: register set 0 -> window 0
+    ld.template commit<0>(G.win0, G.cts);
+    if (i + 2 < npass) ld.template issue<0>(cbase + (int64_t)(i + 2) * G.cts * stride_c, G.cts, min(G.cts, G.nc - (i + 2) * G.cts));
+    __syncthreads();                                   // B(i): window 0 published
+    if (G.nbuf == 1) __syncthreads();                  // single window: wait until the computers are done with it
+    if (i + 1 < npass) {
+      ld.template commit<1>(G.win1, G.cts);
+      if (i + 3 < npass) ld.template issue<1>(cbase + (int64_t)(i + 3) * G.cts * stride_c, G.cts, min(G.cts, G.nc - (i + 3) * G.cts));
+      __syncthreads();                                 // B(i+1)
+      if (G.nbuf == 1) __syncthreads();
+    }
+  }
+}
+
+template <typename TOut>
+__device__ __forceinline__ void ws_compute_role(const WsGeom& G, TOut* out) {
+  const int ctid = threadIdx.x - kWsLoaders;
+  const int w = ctid >> 6, lane = ctid & 63;            // compute wave w <-> channel quad w of the sub-tile
+  const int quads = G.cts >> 2;                         // 4 (cts 16) or 2 (cts 8): waves >= quads idle in compute
+  float* slab = G.slabs + w * 4 * G.bins;
+  const int npass = ceil_div(G.nc, G.cts);
+  for (int i = 0; i < npass; i++) {
+    __syncthreads();                                    // B(i): this sub-tile's window is published
+    const float* wq = ((i & 1) ? G.win1 : G.win0) + w * 4;
+    const int cs = i * G.cts + w * 4;                   // first channel (inside the workgroup's block) of my quad
+    if (w < quads && cs < G.nc) {
+      for (int bin = lane; bin < G.bins; bin += 64) {
+        const int ph = bin / G.pooled_w, pw = bin - ph * G.pooled_w;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (G.gh == 2 && G.gw == 2) {
+          const LdsAxis x0e = G.xtab[pw * 2], x1e = G.xtab[pw * 2 + 1];
+          const LdsAxis y0e = G.ytab[ph * 2], y1e = G.ytab[ph * 2 + 1];
+          float4 t[16];
+          t[0] = *reinterpret_cast<const float4*>(wq + y0e.lo + x0e.lo); t[1] = *reinterpret_cast<const float4*>(wq + y0e.lo + x0e.hi);
+          t[2] = *reinterpret_cast<const float4*>(wq + y0e.hi + x0e.lo); t[3] = *reinterpret_cast<const float4*>(wq + y0e.hi + x0e.hi);
+          t[4] = *reinterpret_cast<const float4*>(wq + y0e.lo + x1e.lo); t[5] = *reinterpret_cast<const float4*>(wq + y0e.lo + x1e.hi);
+          t[6] = *reinterpret_cast<const float4*>(wq + y0e.hi + x1e.lo); t[7] = *reinterpret_cast<const float4*>(wq + y0e.hi + x1e.hi);
+          t[8] = *reinterpret_cast<const float4*>(wq + y1e.lo + x0e.lo); t[9] = *reinterpret_cast<const float4*>(wq + y1e.lo + x0e.hi);
+          t[10] = *reinterpret_cast<const float4*>(wq + y1e.hi + x0e.lo); t[11] = *reinterpret_cast<const float4*>(wq + y1e.hi + x0e.hi);
+          t[12] = *reinterpret_cast<const float4*>(wq + y1e.lo + x1e.lo); t[13] = *reinterpret_cast<const float4*>(wq + y1e.lo + x1e.hi);
+          t[14] = *reinterpret_cast<const float4*>(wq + y1e.hi + x1e.lo); t[15] = *reinterpret_cast<const float4*>(wq + y1e.hi + x1e.hi);
+#pragma unroll
+          for (int sidx = 0; sidx < 4; sidx++) {   // (iy, ix) = (0,0) (0,1) (1,0) (1,1): the reference's accumulation order
+            const LdsAxis& y = (sidx < 2) ? y0e : y1e;
+            const LdsAxis& x = (sidx & 1) ? x1e : x0e;
+            const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;      // roi_align_cpu_loop.cpp:95
+            const float4 v1 = t[sidx * 4], v2 = t[sidx * 4 + 1], v3 = t[sidx * 4 + 2], v4 = t[sidx * 4 + 3];
+            a0 += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;                              // :208-211
+            a1 += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+            a2 += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+            a3 += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+          }
+        } else {
+          for (int iy = 0; iy < G.gh; iy++) {
+            const LdsAxis y = G.ytab[ph * G.gh + iy];
+            for (int ix = 0; ix < G.gw; ix++) {
+              const LdsAxis x = G.xtab[pw * G.gw + ix];
+              const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;
+              const float4 v1 = *reinterpret_cast<const float4*>(wq + y.lo + x.lo);
+              const float4 v2 = *reinterpret_cast<const float4*>(wq + y.lo + x.hi);
+              const float4 v3 = *reinterpret_cast<const float4*>(wq + y.hi + x.lo);
+              const float4 v4 = *reinterpret_cast<const float4*>(wq + y.hi + x.hi);
+              a0 += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+              a1 += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+              a2 += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+              a3 += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+            }
+          }
+        }
+        float* so = slab + bin;
+        if (G.inv_count != 0.f) { so[0] = a0 * G.inv_count; so[G.bins] = a1 * G.inv_count; so[2 * G.bins] = a2 * G.inv_count; so[3 * G.bins] = a3 * G.inv_count; }
+        else { so[0] = fdiv(a0, G.count); so[G.bins] = fdiv(a1, G.count); so[2 * G.bins] = fdiv(a2, G.count); so[3 * G.bins] = fdiv(a3, G.count); }   // :216
+      }
+      // private slab: LDS operations of ONE wave complete in issue order, so after the wait every lane sees the wave's writes
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const int nch = min(4, G.nc - cs);
+      const int n_out = nch * G.bins;
+      TOut* og = out + (size_t)cs * G.bins;
+      if (sizeof(TOut) == 4 && ((reinterpret_cast<uintptr_t>(og) & 15) == 0)) {
+        const int n4 = n_out >> 2;
+        for (int j = lane; j < n4; j += 64) reinterpret_cast<float4*>(og)[j] = reinterpret_cast<const float4*>(slab)[j];
+        for (int j = (n4 << 2) + lane; j < n_out; j += 64) og[j] = from_f32<TOut>(slab[j]);
+      } else {
+        for (int j = lane; j < n_out; j += 64) og[j] = from_f32<TOut>(slab[j]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next sub-tile overwrites it
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (G.nbuf == 1) __syncthreads();                   // single window: hand it back to the loaders
+  }
+}
+
+#ifndef DTC_WS_MINW
+#define DTC_WS_MINW 4
+#endif
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(kWsThreads, DTC_WS_MINW) void roi_align_fwd_ws(RoiAlignParams p, int lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* lds = reinterpret_cast<float*>(smem);
+  AxisEntry* ytab = reinterpret_cast<AxisEntry*>(smem);
+  const int nct = ceil_div(p.channels, p.ch_block);
+  const int ri = blockIdx.x / nct;
+  const int c0 = (blockIdx.x - ri * nct) * p.ch_block;
+  const int nc = min(p.ch_block, p.channels - c0);
+  const int bins = p.pooled_h * p.pooled_w;
+  const int tid = threadIdx.x;
+  const RoiHead hd = load_roi_head(p, ri);
+  const int r = hd.r, lvl = hd.lvl, b = hd.b;
+  TOut* out = reinterpret_cast<TOut*>(p.out) + ((size_t)r * p.channels + c0) * bins;
+  if (lvl < 0 || lvl >= p.n_levels) {
+    for (int o = tid; o < nc * bins; o += kWsThreads) out[o] = from_f32<TOut>(0.f);
+    return;
+  }
+  const dtc_feat_level L = p.lv[lvl];
+  const float sw = hd.sw, sh = hd.sh, bin_h = hd.bin_h, bin_w = hd.bin_w, count = hd.count;
+  const int gh = hd.gh, gw = hd.gw;
+  const int ny = p.pooled_h * gh, nx = p.pooled_w * gw;
+  const bool tab_ok = (ny + nx) * 4 <= kLdsTableFloats;
+  AxisEntry* xtab = ytab + ny;
+  if (tab_ok) {
+    for (int t = tid; t < ny + nx; t += kWsThreads) {
+      if (t < ny) ytab[t] = make_axis(sh, bin_h, t / gh, t % gh, gh, L.height);
+      else { const int u = t - ny; xtab[u] = make_axis(sw, bin_w, u / gw, u % gw, gw, L.width); }
+    }
+  }
+  __syncthreads();
+  const TIn* fbase = reinterpret_cast<const TIn*>(L.data) + (int64_t)b * L.stride_n;
+  int y0 = 0, x0 = 0, ww = 1, wh = 1, npix = 0, cts = 0, nbuf = 0;
+  const int slab_floats = 4 * 4 * bins;                 // 4 compute waves x [4][bins]
+  if (tab_ok) {
+    y0 = ytab[0].lo; x0 = xtab[0].lo;
+    ww = xtab[nx - 1].hi - x0 + 1; wh = ytab[ny - 1].hi - y0 + 1;
+    npix = ww * wh;
+    const int avail = lds_floats - kLdsTableFloats - slab_floats;
+    // prefer two windows of 16 channels, then one window of 16, then one of 8; per-thread share <= 32 registers per set
+    if (npix <= kLdsMaxPix) {
+      if (npix * 16 <= 8192 && 2 * (npix + 1) * (16 + kLdsPad) <= avail) { cts = 16; nbuf = 2; }
+      else if (npix * 16 <= 8192 && (npix + 1) * (16 + kLdsPad) <= avail) { cts = 16; nbuf = 1; }
+      else if (2 * (npix + 1) * (8 + kLdsPad) <= avail) { cts = 8; nbuf = 2; }
+      else if ((npix + 1) * (8 + kLdsPad) <= avail) { cts = 8; nbuf = 1; }
+    }
+  }
+  if (cts == 0) {
+    for (int o = tid; o < nc * bins; o += kWsThreads) {   // oversize window / grid: per-output gather (same arithmetic)
+      const int c = o / bins, bin = o - c * bins;
+      const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
+      const TIn* d = fbase + (int64_t)(c0 + c) * L.stride_c;
+      float acc = 0.f;
+      for (int iy = 0; iy < gh; iy++) {
+        const AxisEntry y = tab_ok ? ytab[ph * gh + iy] : make_axis(sh, bin_h, ph, iy, gh, L.height);
+        const int64_t ylo = (int64_t)y.lo * L.stride_h, yhi = (int64_t)y.hi * L.stride_h;
+        for (int ix = 0; ix < gw; ix++) {
+          const AxisEntry x = tab_ok ? xtab[pw * gw + ix] : make_axis(sw, bin_w, pw, ix, gw, L.width);
+          const int64_t xlo = (int64_t)x.lo * L.stride_w, xhi = (int64_t)x.hi * L.stride_w;
+          const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;
+          acc += w1 * to_f32<TIn>(d[ylo + xlo]) + w2 * to_f32<TIn>(d[ylo + xhi]) + w3 * to_f32<TIn>(d[yhi + xlo]) +
+                 w4 * to_f32<TIn>(d[yhi + xhi]);
+        }
+      }
+      out[o] = from_f32<TOut>(fdiv(acc, count));
+    }
+    return;
+  }
+  __syncthreads();
+  const int ctp = cts + kLdsPad;
+  LdsAxis* yl = reinterpret_cast<LdsAxis*>(ytab);
+  LdsAxis* xl = reinterpret_cast<LdsAxis*>(xtab);
+  if (tid < ny) { AxisEntry e = ytab[tid]; LdsAxis o; o.lo = (e.lo - y0) * ww * ctp; o.hi = (e.hi - y0) * ww * ctp; o.l = e.l; o.h = e.h; yl[tid] = o; }
+  else if (tid < ny + nx) { AxisEntry e = ytab[tid]; LdsAxis o; o.lo = (e.lo - x0) * ctp; o.hi = (e.hi - x0) * ctp; o.l = e.l; o.h = e.h; yl[tid] = o; }
+  WsGeom G;
+  G.ytab = yl; G.xtab = xl;
+  G.slabs = lds + kLdsTableFloats;
+  G.win0 = G.slabs + slab_floats;
+  G.win1 = nbuf == 2 ? G.win0 + (npix + 1) * ctp : G.win0;
+  G.cts = cts; G.bins = bins; G.gh = gh; G.gw = gw; G.pooled_w = p.pooled_w; G.nc = nc; G.nbuf = nbuf;
+  G.count = count; G.inv_count = hd.inv_count;
+  __syncthreads();                                      // tables rewritten
+  if (tid < kWsLoaders) {
+    const TIn* cbase = fbase + (int64_t)c0 * L.stride_c;
+    const int nk = ceil_div(ceil_div(npix, 16), kWsLoaders / 64);
+    if (nk <= 4) { WsLoader<TIn, 4, 4> ld; ld.init(L, y0, x0, ww, wh, npix, cts); ws_loader_role<TIn>(ld, G, cbase, L.stride_c); }
+    else if (nk <= 8) { WsLoader<TIn, 8, 4> ld; ld.init(L, y0, x0, ww, wh, npix, cts); ws_loader_role<TIn>(ld, G, cbase, L.stride_c); }
+    else { WsLoader<TIn, 16, 2> ld; ld.init(L, y0, x0, ww, wh, npix, cts); ws_loader_role<TIn>(ld, G, cbase, L.stride_c); }
+  } else {
+    ws_compute_role<TOut>(G, out);
+  }
+}
+
+template <typename TIn, typename TOut>
+static int launch_ws(const RoiAlignParams& p, hipStream_t stream, int lds_b) {
+  if (p.n_rois == 0) return DTC_OK;
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_ws<TIn, TOut>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
+    raised = true;
+  }
+  const int nct = ceil_div(p.channels, p.ch_block);
+  hipLaunchKernelGGL((roi_align_fwd_ws<TIn, TOut>), dim3((unsigned)p.n_rois * nct), dim3(kWsThreads), lds_b, stream, p,
+                     lds_b / 4);
+  DTC_CHECK_LAUNCH();
+  return DTC_OK;
+}
+
 static int lds_bytes();
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -906,6 +1210,16 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   // LDS-DMA variant: bit-exact and tested, but SLOWER on MI355X than the register-prefetch kernel (8000 RoIs: 0.84 vs
   // 0.71 ms): with 4 bytes per lane a `global_load_lds_dword` moves only 256 B per instruction and a workgroup needs ~1200 of
   // them per RoI -- the DMA issue rate, not bytes in flight, becomes the limit.  Kept behind DTC_ROIALIGN_DMA=1 for A/B runs.
+  // Wave-specialised variant (loader waves / compute waves, double-buffered windows): bit-exact and tested, measured
+  // 0.84 ms vs 0.80 ms for the default kernel on the same box (512-thread workgroups at 128 VGPRs -> 2 workgroups per CU;
+  // with two register sets and 194 VGPRs only one workgroup fits: 1.05 ms).  Kept behind DTC_ROIALIGN_WS=1 for A/B runs.
+  if (lds_ok && !all_nhwc && getenv("DTC_ROIALIGN_WS") != nullptr) {
+    const int lds_b = dtc::lds_bytes();
+    if (in_dtype == DTC_F32 && out_dtype == DTC_F32) return dtc::launch_ws<float, float>(p, s, lds_b);
+    if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return dtc::launch_ws<__half, float>(p, s, lds_b);
+    if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return dtc::launch_ws<__half, __half>(p, s, lds_b);
+    if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return dtc::launch_ws<float, __half>(p, s, lds_b);
+  }
   if (lds_ok && in_dtype == DTC_F32 && !all_nhwc && getenv("DTC_ROIALIGN_DMA") != nullptr) {
     int lds_b = dtc::lds_bytes();
     if (out_dtype == DTC_F32) return dtc::launch_dma<float>(p, s, lds_b);

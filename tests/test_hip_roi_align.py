@@ -177,3 +177,15 @@ def test_ordered_and_packed_entry_points(hip, oracle):
     assert rc == 0
     res = outp.cpu().numpy()
     assert np.array_equal(res[:200], ref) and not res[200].any()
+
+
+@pytest.mark.parametrize("env", ["DTC_ROIALIGN_WS", "DTC_ROIALIGN_DMA", "DTC_ROIALIGN_GENERAL"])
+def test_experimental_kernel_variants_bit_exact(hip, oracle, env, monkeypatch):
+    """The env-selected RoIAlign variants kept in the library (wave-specialised loader/compute kernel, LDS-DMA staging, the
+    general gather kernel) do the same arithmetic in the same order: bit-identical to the oracle, incl. channel tails."""
+    monkeypatch.setenv(env, "1")                         # read with getenv() at every dispatch
+    for (C, ph, sr, R, seed) in [(32, 7, 2, 200, 5), (130, 7, 2, 60, 6), (24, 14, 2, 60, 8), (20, 7, 0, 60, 9)]:
+        feats, rois5, lv, ref = _fpn_case(oracle, R, C, ph, sr, seed, batch=2)
+        out = hip.roi_align_forward([cu(f) for f in feats], synth.FPN_ROI_SCALES, cu(rois5), ph, ph, sr,
+                                    roi_levels=cu(lv)).cpu().numpy()
+        assert np.array_equal(out, ref), (env, C, ph, sr)
