@@ -29,7 +29,23 @@ struct RoiAlignParams {
   void* out;
   int n_levels, channels, roi_cols, n_rois, pooled_h, pooled_w, sampling_ratio, ch_tile;
   int ch_block;   // channels per workgroup of the LDS kernel (multiple of 64): setup (tables, window) is paid once per block
+  int cts64;      // 1: allow 64-channel sub-tiles (one bin per ds_read_b128 lane group: conflict-free taps)
+  int row4;       // 1: 16-byte row pieces for NCHW levels whose rows are 4-element aligned (StagerRow4)
+  int xcd_remap;  // 1: workgroup -> work-item mapping keeps each XCD on a contiguous range of the visiting order
 };
+
+// XCD-aware work assignment.  The dispatcher deals workgroups round-robin over the 8 XCDs (workgroup b runs on XCD b % 8)
+// and each XCD has its own 4 MB L2.  RoIs are visited in (level, y) order so that neighbours share feature rows; with the
+// identity mapping those neighbours land on 8 different L2s and every feature line is pulled through the fabric once per
+// XCD that touches it.  Remapped, XCD x owns the contiguous slice [start(x), start(x+1)) of the visiting order and walks
+// it front to back: a line is fetched by one L2 (two at a slice boundary).  Bijective for any grid size.
+constexpr int kXcds = 8;
+__device__ __forceinline__ int xcd_work_item(int b, int n, int enabled) {
+  if (!enabled || n < 2 * kXcds) return b;
+  const int x = b % kXcds, j = b / kXcds;
+  const int q = n / kXcds, r = n - q * kXcds;
+  return x * q + min(x, r) + j;
+}
 
 // One axis of pre_calc_for_bilinear_interpolate (roi_align_cpu_loop.cpp:36-93).
 struct AxisEntry {
@@ -315,6 +331,70 @@ struct StagerNHWC {
   }
 };
 
+// NCHW, 16-byte row pieces (the default for the reference's layout when rows are 16-byte aligned: stride_w == 1 and
+// W, H*W multiples of 4).  The window is widened to 4-pixel boundaries [xa, xa + 4*ng) and a lane loads FOUR consecutive
+// pixels of one channel row with ONE global_load_dwordx4 (fp16: dwordx2) -- 3.5x fewer vector-memory instructions and
+// L1 accesses than one dword per lane for the same lines (PMC: the dword stager spends ~46 % of the TCP cycles stalled on
+// pending requests).  thread -> fixed channel (tid % cts) x positions (row, 4-pixel group) p0 + k*(256/cts): a wave covers
+// cts channels x 64/cts positions, so the four transposing ds_write_b32 of a piece (pixel stride ctp: 16*(m&1) + channel
+// mod 32 banks) are 2-way = free for cts 32/16.  Padding columns hold real neighbouring pixels; the axis tables are made
+// relative to xa, so the compute phase is unchanged.  At most K = 8 pieces (32 registers) per thread and sub-tile.
+template <typename TIn>
+struct StagerRow4 {
+  static constexpr int K = 8;
+  float4 v[K];
+  uint32_t voff[K];
+  int32_t lbase[K];
+  int nk, ch, ctp;
+  uint32_t okmask;
+  static __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ float4 load4(const __half* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    const __half2 a = *reinterpret_cast<const __half2*>(&r.x), b = *reinterpret_cast<const __half2*>(&r.y);
+    return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
+  }
+  __device__ __forceinline__ void init(const dtc_feat_level& L, int y0, int xa, int ng, int wh, int cts) {
+    const int tid = threadIdx.x;
+    ch = tid & (cts - 1);
+    const int sh = 31 - __clz(cts);                 // cts is a power of two
+    const int p0 = tid >> sh, np = kRoiAlignThreads >> sh;
+    const int npg = wh * ng, wwa = 4 * ng;
+    ctp = cts + kLdsPad;
+    nk = ceil_div(npg, np);
+    const float rinv = 1.0f / (float)ng;
+    okmask = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int pos = p0 + np * k;
+      const bool ok = pos < npg;
+      const int pp = ok ? pos : npg - 1;
+      const int row = (int)(((float)pp + 0.5f) * rinv);   // exact for pp < 2^12 (distance to an integer boundary >= 0.5/ng)
+      const int g = pp - row * ng;
+      okmask |= ok ? (1u << k) : 0u;
+      voff[k] = (uint32_t)(((int64_t)(y0 + row) * L.stride_h + (int64_t)(xa + 4 * g) + (int64_t)ch * L.stride_c) *
+                           (int64_t)sizeof(TIn));
+      lbase[k] = (row * wwa + 4 * g) * ctp + ch;
+    }
+  }
+  __device__ __forceinline__ void issue(const TIn* cbase, int cts, int nvalid) {
+    const char* cb = reinterpret_cast<const char*>(cbase);
+    if (ch < nvalid) {      // channel tail: planes past the end are not read; their LDS columns are never stored
+#pragma unroll
+      for (int k = 0; k < K; k++)
+        if (k < nk && ((okmask >> k) & 1u)) v[k] = load4(reinterpret_cast<const TIn*>(cb + voff[k]));
+    }
+  }
+  __device__ __forceinline__ void commit(float* win, int cts) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      if (k < nk && ((okmask >> k) & 1u)) {
+        float* d = win + lbase[k];
+        d[0] = v[k].x; d[ctp] = v[k].y; d[2 * ctp] = v[k].z; d[3 * ctp] = v[k].w;
+      }
+    }
+  }
+};
+
 // axis-table entry of the LDS kernel: window-relative, premultiplied
 struct LdsAxis { int lo, hi; float l, h; };   // y: (row - y0) * ww * ctp ; x: (col - x0) * ctp   [LDS words]
 
@@ -329,7 +409,13 @@ template <typename TIn, typename TOut, typename Stager>
 __device__ __forceinline__ void run_passes(Stager& st, const LdsGeom& G, const TIn* fbase0, int64_t stride_c, TOut* out) {
   const int tid = threadIdx.x;
   const int quads = G.cts >> 2;
-  const int cq = tid % quads, slot = tid / quads, nslot = kRoiAlignThreads / quads;
+  // ds_read_b128 is serviced in four 16-lane groups {0-3,12-15,20-27} {4-11,16-19,28-31} (+32): number the lanes group by
+  // group so that the lanes of one hardware group read as few different pixels as possible (16 quads: ONE pixel = 16
+  // consecutive 16-byte units = conflict-free; 8 quads: two pixels instead of four)
+  const int ln = tid & 63, lq = (ln >> 2) & 7;
+  const int grp = (lq ^ (lq >> 1) ^ (lq >> 2)) & 1;                        // parity of the quad index
+  const int vt = (tid & ~63) | (ln & 32) | (grp << 4) | ((ln >> 3) & 3) << 2 | (ln & 3);
+  const int cq = vt % quads, slot = vt / quads, nslot = kRoiAlignThreads / quads;
   const float* wq = G.win + cq * 4;
   st.issue(fbase0, G.cts, min(G.cts, G.nc));
   for (int cs = 0; cs < G.nc; cs += G.cts) {
@@ -390,8 +476,9 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   AxisEntry* ytab = reinterpret_cast<AxisEntry*>(smem);
 
   const int nct = ceil_div(p.channels, p.ch_block);
-  const int ri = blockIdx.x / nct;
-  const int c0 = (blockIdx.x - ri * nct) * p.ch_block;
+  const int wi = xcd_work_item(blockIdx.x, gridDim.x, p.xcd_remap);
+  const int ri = wi / nct;
+  const int c0 = (wi - ri * nct) * p.ch_block;
   const int nc = min(p.ch_block, p.channels - c0);
   const int bins = p.pooled_h * p.pooled_w;
   const int tid = threadIdx.x;
@@ -438,12 +525,31 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
     }
     return;
   }
-  const int y0 = ytab[0].lo, y1 = ytab[ny - 1].hi, x0 = xtab[0].lo, x1 = xtab[nx - 1].hi;
-  const int ww = x1 - x0 + 1, wh = y1 - y0 + 1, npix = wh * ww;
+  const int y0 = ytab[0].lo, y1 = ytab[ny - 1].hi, x1 = xtab[nx - 1].hi;
+  int x0 = xtab[0].lo;
+  int ww = x1 - x0 + 1;
+  const int wh = y1 - y0 + 1;
+  int npix = wh * ww;
   // sub-tile width: largest CTs whose window (+1 dummy pixel) + output slab fit
   const int avail = lds_floats - kLdsTableFloats;
-  // ... and whose per-thread share of the window fits the 32 prefetch registers (npix * cts <= 8192)
   int cts = 0;
+  // 16-byte row pieces (StagerRow4) when every row of this level starts on a 4-element boundary
+  bool row4 = p.row4 && L.stride_w == 1 && ((L.width | L.stride_h | L.stride_c | L.stride_n) & 3) == 0 &&
+              (reinterpret_cast<uintptr_t>(L.data) & (4 * sizeof(TIn) - 1)) == 0;
+  int xa = x0, ng = 0;
+  if (row4) {
+    xa = x0 & ~3;
+    ng = (x1 >> 2) - (x0 >> 2) + 1;
+    const int npg = wh * ng, npa = npg * 4;
+#pragma unroll
+    for (int c = 32; c >= 8; c >>= 1)      // K = 8 pieces per thread: positions <= 8 * 256 / cts
+      if (cts == 0 && npg * c <= 8 * kRoiAlignThreads &&
+          (long long)(npa + 1) * (c + kLdsPad) + (long long)c * bins <= avail) cts = c;
+    if (cts != 0) { x0 = xa; ww = 4 * ng; npix = npa; } else row4 = false;
+  }
+  // ... otherwise one dword per lane; the per-thread share of the window must fit the 32 prefetch registers (npix * cts <= 8192)
+  if (p.cts64 && cts == 0 && L.stride_c != 1 && nc >= 64 && npix <= 128 &&
+      (long long)(npix + 1) * (64 + kLdsPad) + 64LL * bins <= avail) cts = 64;
 #pragma unroll
   for (int c = 32; c >= 8; c >>= 1)
     if (cts == 0 && npix <= kLdsMaxPix && npix * c <= 8192 &&
@@ -483,12 +589,16 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   G.cts = cts; G.bins = bins; G.gh = gh; G.gw = gw; G.pooled_w = p.pooled_w; G.nc = nc; G.count = count;
   G.inv_count = hd.inv_count;
   const TIn* cbase = fbase + (int64_t)c0 * L.stride_c;
-  if (L.stride_c == 1) {
+  if (row4) {
+    StagerRow4<TIn> st; st.init(L, y0, xa, ng, wh, cts);
+    run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out);
+  } else if (L.stride_c == 1) {
     StagerNHWC<TIn> st; st.init(L, y0, x0, ww, wh, npix, cts);
     run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out);
   } else {
     const int nk = ceil_div(ceil_div(npix, 16), kRoiAlignThreads / 64);
-    if (nk <= 4) { StagerNCHW<TIn, 4, 8> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
+    if (cts == 64) { StagerNCHW<TIn, 2, 16> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
+    else if (nk <= 4) { StagerNCHW<TIn, 4, 8> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
     else if (nk <= 8) { StagerNCHW<TIn, 8, 4> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
     else { StagerNCHW<TIn, 16, 2> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
   }
@@ -523,8 +633,9 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
   AxisEntry* ytab = reinterpret_cast<AxisEntry*>(smem);
   float* slab = reinterpret_cast<float*>(smem) + kLdsTableFloats;
   const int nct = ceil_div(p.channels, 64);
-  const int ri = blockIdx.x / nct;
-  const int c0 = (blockIdx.x - ri * nct) * 64;
+  const int wi = xcd_work_item(blockIdx.x, gridDim.x, p.xcd_remap);
+  const int ri = wi / nct;
+  const int c0 = (wi - ri * nct) * 64;
   const int nc = min(64, p.channels - c0);
   const int bins = p.pooled_h * p.pooled_w;
   const int tid = threadIdx.x;
@@ -844,8 +955,9 @@ __global__ __launch_bounds__(kWsThreads, DTC_WS_MINW) void roi_align_fwd_ws(RoiA
   float* lds = reinterpret_cast<float*>(smem);
   AxisEntry* ytab = reinterpret_cast<AxisEntry*>(smem);
   const int nct = ceil_div(p.channels, p.ch_block);
-  const int ri = blockIdx.x / nct;
-  const int c0 = (blockIdx.x - ri * nct) * p.ch_block;
+  const int wi = xcd_work_item(blockIdx.x, gridDim.x, p.xcd_remap);
+  const int ri = wi / nct;
+  const int c0 = (wi - ri * nct) * p.ch_block;
   const int nc = min(p.ch_block, p.channels - c0);
   const int bins = p.pooled_h * p.pooled_w;
   const int tid = threadIdx.x;
@@ -978,8 +1090,9 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_dma(RoiAlignPa
   float* lds = reinterpret_cast<float*>(smem);
   AxisEntry* ytab = reinterpret_cast<AxisEntry*>(smem);
   const int nct = ceil_div(p.channels, p.ch_block);
-  const int ri = blockIdx.x / nct;
-  const int c0 = (blockIdx.x - ri * nct) * p.ch_block;
+  const int wi = xcd_work_item(blockIdx.x, gridDim.x, p.xcd_remap);
+  const int ri = wi / nct;
+  const int c0 = (wi - ri * nct) * p.ch_block;
   const int nc = min(p.ch_block, p.channels - c0);
   const int bins = p.pooled_h * p.pooled_w;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1187,6 +1300,9 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   p.ch_block = channels > 64 ? 128 : 64;
   if ((long long)n_rois * ((channels + p.ch_block - 1) / p.ch_block) < 3072) p.ch_block = 64;
   if (getenv("DTC_RA_CHBLOCK")) p.ch_block = atoi(getenv("DTC_RA_CHBLOCK"));
+  p.xcd_remap = getenv("DTC_RA_NO_XCD") == nullptr;
+  p.row4 = getenv("DTC_RA_ROW4") != nullptr;      // measured neutral (0.73 vs 0.71 ms): off by default, A/B knob
+  p.cts64 = getenv("DTC_RA_CTS64") != nullptr;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // fixed sampling grid with small tables -> LDS-staged kernel; adaptive sampling (sampling_ratio <= 0) -> general kernel
   // LDS-staged kernel for every pooled size whose output slab fits; adaptive sampling (sampling_ratio <= 0) included
