@@ -35,6 +35,7 @@ struct RpnLevelDev {
   int chunk_begin;      // first chunk id of this level inside one image
   int tie_begin;        // offset of this level's tie list inside one image's tie buffer
   float feat_stride;
+  int logit;            // scores are pre-sigmoid logits (detector.py:125 folded into this path): see TieBand
   float anchors[kRpnMaxAnchors * 4];  // base anchors, float32 (exact: integers / half-integers)
 };
 
@@ -70,6 +71,47 @@ __device__ __forceinline__ SelState load_state(const RpnParams& p, int seg, uint
   if (PASSES >= 2) { select_digit(H + kHistBins, kHistBins, st.krem, sh); st.p1 = sh[0]; st.krem = sh[1]; __syncthreads(); }
   if (PASSES >= 3) { select_digit(H + 2 * kHistBins, 1024, st.krem, sh); st.p2 = sh[0]; st.krem = sh[1]; __syncthreads(); }
   return st;
+}
+
+// ---- RPN-head epilogue fusion: scores handed over as LOGITS ----------------------------------------------
+// The reference ranks sigmoid(logit) (detector.py:125 -> generate_proposals.py:77-86).  sigmoid is monotone, so the radix
+// select runs on the raw logits untouched; but float32 sigmoid is many-to-one (every logit > 16.7 gives 1.0f), and equal
+// PROBABILITIES must tie-break by index exactly as if the probabilities had been materialised.  After the select has found
+// the K-th largest logit T, the band [lo, hi] of logits whose probability equals P* = sigmoid(T) is located by bisection on
+// the ordered keys (sigmoid evaluated in double and rounded once: the same value oracle/numpy produce): logits above the
+// band are certainly selected (their sort key carries their probability), logits inside it are the ties, the rest is out.
+// Only the K selected elements ever get a sigmoid evaluated -- the [B,A,H,W] probability map is never written or read.
+__device__ __forceinline__ float sigmoid_cr(float x) {
+  return (float)(1.0 / (1.0 + exp(-(double)x)));
+}
+struct TieBand { uint32_t lo, hi; float p; };   // ordered-key band of the threshold score and the score itself
+
+// one wave: lane 0 bisects upwards, lane 1 downwards; result broadcast through sh3[3].  Call from all threads of the block.
+__device__ __forceinline__ TieBand tie_band(uint32_t T, bool logit, uint32_t* sh3) {
+  TieBand tb;
+  if (!logit) { tb.lo = tb.hi = T; tb.p = ordered_to_float(T); return tb; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const float pt = sigmoid_cr(ordered_to_float(T));
+    const uint32_t pk = float_to_ordered(pt);
+    const bool up = threadIdx.x == 0;
+    // invariant: f(a) == pk, f(b) != pk (b is outside the band or the end of the finite range)
+    uint32_t a = T;
+    uint32_t b = up ? float_to_ordered(__uint_as_float(0x7f800000u)) : float_to_ordered(__uint_as_float(0xff800000u));
+    if (float_to_ordered(sigmoid_cr(ordered_to_float(b))) == pk) a = b;      // band reaches +-inf
+    else {
+      while ((up ? b - a : a - b) > 1u) {
+        const uint32_t m = up ? a + ((b - a) >> 1) : a - ((a - b) >> 1);
+        if (float_to_ordered(sigmoid_cr(ordered_to_float(m))) == pk) a = m; else b = m;
+      }
+    }
+    sh3[up ? 1 : 0] = a;
+    if (up) sh3[2] = __float_as_uint(pt);
+  }
+  __syncthreads();
+  tb.lo = sh3[0]; tb.hi = sh3[1]; tb.p = __uint_as_float(sh3[2]);
+  __syncthreads();
+  return tb;
 }
 
 template <int PASS>
@@ -116,10 +158,11 @@ __global__ __launch_bounds__(kHistThreads) void rpn_compact_kernel(RpnParams p) 
   const int chunk = blockIdx.x - L.chunk_begin;
   const bool take_all = L.K >= L.N;
   if (threadIdx.x < 2) lcnt[threadIdx.x] = 0;
-  uint32_t T = 0;
+  __shared__ uint32_t sh3[3];
+  TieBand tb; tb.lo = tb.hi = 0; tb.p = 0.f;
   if (!take_all) {
     const SelState st = load_state<3>(p, seg, (uint32_t)L.K, sh);
-    T = (st.p0 << 21) | (st.p1 << 10) | st.p2;
+    tb = tie_band((st.p0 << 21) | (st.p1 << 10) | st.p2, L.logit != 0, sh3);
   }
   __syncthreads();
   const float* sc = L.cls + (size_t)b * L.N;
@@ -128,13 +171,13 @@ __global__ __launch_bounds__(kHistThreads) void rpn_compact_kernel(RpnParams p) 
   for (int i = begin + threadIdx.x; i < end; i += kHistThreads) {
     const float s = sc[i];
     const uint32_t o = float_to_ordered(s);
-    const bool is_gt = take_all || o > T;
-    const bool is_tie = !take_all && o == T;
+    const bool is_gt = take_all || o > tb.hi;
+    const bool is_tie = !take_all && o >= tb.lo && o <= tb.hi;
     if (is_gt || is_tie) {
       // memory index i = (a*H + h)*W + w  ->  canonical index n = (h*W + w)*A + a   (generate_proposals.py:64,72)
       const int a = i / HW, hw = i - a * HW;
       const uint32_t n = (uint32_t)(hw * L.A + a);
-      if (is_gt) gt_s[atomicAdd(&lcnt[0], 1u)] = make_desc_key(s, n);
+      if (is_gt) gt_s[atomicAdd(&lcnt[0], 1u)] = make_desc_key(L.logit ? sigmoid_cr(s) : s, n);
       else tie_s[atomicAdd(&lcnt[1], 1u)] = n;
     }
   }
@@ -187,6 +230,7 @@ __global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_decode_kernel(Rpn
   if (n_tie) {  // all ties share the threshold score: recover it from the selection state
     const SelState st = load_state<3>(p, seg, (uint32_t)K, sh);
     tie_score = ordered_to_float((st.p0 << 21) | (st.p1 << 10) | st.p2);
+    if (L.logit) tie_score = sigmoid_cr(tie_score);     // == TieBand::p of the compaction pass
   }
   uint32_t idx_limit = 0xffffffffu;  // ties with canonical index <= idx_limit are taken
   uint32_t n_take = n_tie;
@@ -250,7 +294,7 @@ __global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_decode_kernel(Rpn
       const uint32_t n = desc_key_index(keys[k]);
       const int a = n % L.A, hw = n / L.A;
       const int h = hw / L.W, w = hw - h * L.W;
-      s = sc[(size_t)a * HW + hw];
+      s = L.logit ? desc_key_score(keys[k]) : sc[(size_t)a * HW + hw];
       // :124-149 shifted anchor: float64 add of exactly representable values, rounded to float32 (:54) -> exact
       const float sx = (float)w * L.feat_stride, sy = (float)h * L.feat_stride;
       const float ax1 = L.anchors[a * 4 + 0] + sx, ay1 = L.anchors[a * 4 + 1] + sy;
@@ -315,7 +359,7 @@ static int make_plan(const dtc_rpn_level* levels, int n_levels, int batch, int k
     if (p) {
       RpnLevelDev& d = p->lv[l];
       d.cls = s.cls_prob; d.bbox = s.bbox_pred; d.A = s.num_anchors; d.H = s.height; d.W = s.width; d.N = (int)N; d.K = K;
-      d.chunk_begin = chunks; d.tie_begin = ties; d.feat_stride = s.feat_stride;
+      d.chunk_begin = chunks; d.tie_begin = ties; d.feat_stride = s.feat_stride; d.logit = s.score_is_logit != 0;
       for (int i = 0; i < s.num_anchors * 4; i++) d.anchors[i] = s.anchors[i];
     }
     chunks += (int)((N + kChunk - 1) / kChunk);

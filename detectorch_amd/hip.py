@@ -20,7 +20,7 @@ _ERR = {-1: "DTC_EINVAL", -2: "DTC_ELAUNCH", -3: "DTC_EWORKSPACE", -4: "DTC_EUNS
 class RpnLevel(C.Structure):
     """struct dtc_rpn_level (include/detectorch_hip.h)"""
     _fields_ = [("cls_prob", C.c_void_p), ("bbox_pred", C.c_void_p), ("num_anchors", C.c_int32), ("height", C.c_int32),
-                ("width", C.c_int32), ("pre_nms_top_n", C.c_int32), ("feat_stride", C.c_float), ("_pad", C.c_int32),
+                ("width", C.c_int32), ("pre_nms_top_n", C.c_int32), ("feat_stride", C.c_float), ("score_is_logit", C.c_int32),
                 ("anchors", C.c_float * 64)]
 
 
@@ -213,8 +213,9 @@ def nms_sorted(boxes, counts, thresh, max_keep=0, keep_stride=None):
     return keep, cnt[:S]
 
 
-def make_rpn_levels(cls_probs, bbox_preds, anchors, feat_strides, pre_nms_top_n):
-    """lists (one entry per level) of [B,A,H,W] / [B,4A,H,W] float32 CUDA tensors + base anchors [A,4] -> RpnLevel array."""
+def make_rpn_levels(cls_probs, bbox_preds, anchors, feat_strides, pre_nms_top_n, scores_are_logits=False):
+    """lists (one entry per level) of [B,A,H,W] / [B,4A,H,W] float32 CUDA tensors + base anchors [A,4] -> RpnLevel array.
+    scores_are_logits: cls_probs holds the pre-sigmoid RPN logits (dtc_rpn_level.score_is_logit)."""
     n = len(cls_probs)
     arr = (RpnLevel * n)()
     keep_alive = []
@@ -228,7 +229,8 @@ def make_rpn_levels(cls_probs, bbox_preds, anchors, feat_strides, pre_nms_top_n)
         a = [float(v) for v in anchors[k].reshape(-1)]
         if len(a) != 4 * A or A > 16:
             raise ValueError("need A<=16 base anchors of 4 coordinates")
-        lv = RpnLevel(c.data_ptr(), d.data_ptr(), A, H, W, int(pre_nms_top_n[k]), float(feat_strides[k]), 0)
+        lv = RpnLevel(c.data_ptr(), d.data_ptr(), A, H, W, int(pre_nms_top_n[k]), float(feat_strides[k]),
+                      1 if scores_are_logits else 0)
         for q, v in enumerate(a):
             lv.anchors[q] = v
         arr[k] = lv
@@ -237,8 +239,10 @@ def make_rpn_levels(cls_probs, bbox_preds, anchors, feat_strides, pre_nms_top_n)
 
 
 def generate_proposals(cls_probs, bbox_preds, anchors, feat_strides, im_h, im_w, pre_nms_top_n, post_nms_top_n,
-                       nms_thresh, min_size_scaled=0.0):
+                       nms_thresh, min_size_scaled=0.0, scores_are_logits=False):
     """Batched multi-level GenerateProposals (generate_proposals.py:31-122) with zero host round trips.
+    scores_are_logits=True folds the RPN head's sigmoid (detector.py:125) into the top-k: pass the raw logits, get the
+    proposals and PROBABILITY scores the reference would produce from sigmoid(logits), without materialising them.
 
     Returns (boxes [B,L,P,4], scores [B,L,P], counts int32 [B,L]) with P = post_nms_top_n (rows >= count undefined),
     plus the pre-NMS (sorted) boxes/scores/counts for callers that want them.
@@ -247,7 +251,7 @@ def generate_proposals(cls_probs, bbox_preds, anchors, feat_strides, im_h, im_w,
     L_ = lib()
     nl = len(cls_probs)
     B = cls_probs[0].shape[0]
-    lv, alive = make_rpn_levels(cls_probs, bbox_preds, anchors, feat_strides, pre_nms_top_n)
+    lv, alive = make_rpn_levels(cls_probs, bbox_preds, anchors, feat_strides, pre_nms_top_n, scores_are_logits)
     kmax = 0
     for k in range(nl):
         N = cls_probs[k].shape[1] * cls_probs[k].shape[2] * cls_probs[k].shape[3]

@@ -177,9 +177,12 @@ class rpn_head(nn.Module):
         self.rpn_cls_prob = nn.Conv2d(out_channels, n_anchors, 1)
         self.rpn_bbox_pred = nn.Conv2d(out_channels, 4 * n_anchors, 1)
 
-    def forward(self, x):
+    def forward(self, x, logits=False):
+        """(rpn_cls_probs, rpn_bbox_pred) as detector.py:123-127; logits=True skips the sigmoid (it is folded into the
+        top-k kernel: GenerateProposals(..., scores_are_logits=True))."""
         c = F.relu(self.conv_rpn(x), inplace=True)
-        return torch.sigmoid(self.rpn_cls_prob(c)), self.rpn_bbox_pred(c)
+        s = self.rpn_cls_prob(c)
+        return (s if logits else torch.sigmoid(s)), self.rpn_bbox_pred(c)
 
 
 def _caffe2_name(key):
@@ -207,8 +210,9 @@ class detector(nn.Module):
                  conv_head_layers=['layer4', 'avgpool'], fpn_layers=[], fpn_extra_lvl=True, use_rpn_head=False,
                  use_mask_head=False, mask_head_type='upshare', roi_feature_channels=2048, N_classes=81,
                  detector_pkl_file=None, base_cnn_pkl_file=None, output_prob=True, roi_height=14, roi_width=14,
-                 roi_spatial_scale=0.0625, roi_sampling_ratio=0, channels_last=False):
+                 roi_spatial_scale=0.0625, roi_sampling_ratio=0, channels_last=False, fuse_rpn_sigmoid=True):
         super().__init__()
+        self.fuse_rpn_sigmoid = bool(fuse_rpn_sigmoid)   # extension: RPN sigmoid folded into the top-k kernel (same outputs)
         if train:
             raise NotImplementedError("detectorch_amd.detector is inference-only")
         self.roi_height, self.roi_width = int(roi_height), int(roi_width)
@@ -265,19 +269,20 @@ class detector(nn.Module):
             image = image.contiguous(memory_format=torch.channels_last)
         img_features = self.conv_body(image)
         if self.use_rpn_head and not self.use_fpn_body:
-            rpn_cls_prob, rpn_bbox_pred = self.rpn(img_features)
-            rois, _ = self.proposal_generator(rpn_cls_prob, rpn_bbox_pred, h, w, scaling_factor)
+            rpn_cls_prob, rpn_bbox_pred = self.rpn(img_features, logits=self.fuse_rpn_sigmoid)
+            rois, _ = self.proposal_generator(rpn_cls_prob, rpn_bbox_pred, h, w, scaling_factor,
+                                              scores_are_logits=self.fuse_rpn_sigmoid)
         fused = None
         if self.use_rpn_head and self.use_fpn_body:
             feats = list(img_features)
             if self.fpn_extra_lvl:
                 feats = feats + [F.max_pool2d(feats[-1], 1, stride=2)]                 # detector.py:250
-            cls_bbox = [self.rpn(f) for f in feats]
+            cls_bbox = [self.rpn(f, logits=self.fuse_rpn_sigmoid) for f in feats]
             gens = self.proposal_generator
             boxes, scores, counts, _, _, _ = hip.generate_proposals(                     # all levels, one call
                 [c for c, _ in cls_bbox], [b for _, b in cls_bbox], [g._anchors for g in gens],
                 [1. / s for s in self.rpn_scales], h, w, [g.rpn_pre_nms_top_n for g in gens],
-                gens[0].rpn_post_nms_top_n, gens[0].rpn_nms_thresh)
+                gens[0].rpn_post_nms_top_n, gens[0].rpn_nms_thresh, scores_are_logits=self.fuse_rpn_sigmoid)
             lv = [int(log2(1 / s)) for s in self.roi_spatial_scale]
             fused = hip.fpn_collect_distribute(boxes, scores, counts, 1000, lv[0], lv[-1],   # collect...py:86
                                                inputs_sorted=True)

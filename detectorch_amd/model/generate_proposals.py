@@ -29,7 +29,11 @@ class GenerateProposals(torch.nn.Module):
         self.rpn_nms_thresh = rpn_nms_thresh if rpn_nms_thresh is not None else 0.7
         self.rpn_min_size = rpn_min_size if rpn_min_size is not None else 0
 
-    def forward(self, rpn_cls_probs, rpn_bbox_pred, im_height, im_width, scaling_factor, spatial_scale=None):
+    def forward(self, rpn_cls_probs, rpn_bbox_pred, im_height, im_width, scaling_factor, spatial_scale=None, *,
+                scores_are_logits=False):
+        """Reference signature (generate_proposals.py:31).  Extension (keyword-only): scores_are_logits=True takes the
+        PRE-sigmoid rpn_cls_logits and returns what the reference returns for sigmoid(logits) -- the sigmoid of
+        detector.py:125 is folded into the top-k kernel."""
         if spatial_scale is None:
             spatial_scale = self._spatial_scale
         if rpn_cls_probs.shape[0] != 1:
@@ -39,6 +43,6 @@ class GenerateProposals(torch.nn.Module):
         boxes, scores, counts, _, _, _ = hip.generate_proposals(
             [rpn_cls_probs], [rpn_bbox_pred], [self._anchors], [1. / spatial_scale], im_height, im_width,
             [self.rpn_pre_nms_top_n], self.rpn_post_nms_top_n, self.rpn_nms_thresh,
-            min_size_scaled=self.rpn_min_size * sf)
+            min_size_scaled=self.rpn_min_size * sf, scores_are_logits=scores_are_logits)
         k = int(counts.reshape(-1)[0].item())            # variable-length return value => one sync, as in the reference
         return boxes[0, 0, :k, :], scores[0, 0, :k].unsqueeze(1)

@@ -124,7 +124,10 @@ typedef struct dtc_rpn_level {
   int32_t num_anchors, height, width;
   int32_t pre_nms_top_n;
   float feat_stride;
-  int32_t _pad;
+  int32_t score_is_logit;   /* 0: cls_prob holds probabilities (the reference contract).  1: it holds the PRE-sigmoid logits
+                             * of detector.py:125; ranking, tie-breaking and the emitted scores are those of
+                             * sigmoid(logit) evaluated in double and rounded once -- the probability map is never
+                             * materialised.  Field was padding before: zero-initialised callers are unchanged. */
   float anchors[DTC_RPN_MAX_ANCHORS * 4];
 } dtc_rpn_level;
 

@@ -111,6 +111,14 @@ def soft_nms(dets, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, method="li
     return boxes[:k].copy(), inds[:k].copy()
 
 
+def rpn_sigmoid(logits):
+    """rpn_cls_probs = sigmoid(rpn_cls_logits) (reference: lib/model/detector.py:125, F.sigmoid on float32).  Restated as the
+    correctly-rounded value (evaluate in float64, round once) so that the checker does not depend on a libm's float32
+    ulp behaviour; torch's own float32 sigmoid is within 2 ulp of it (checked in tests/test_oracle_golden.py)."""
+    x = np.asarray(logits, np.float32).astype(np.float64)
+    return (1.0 / (1.0 + np.exp(-x))).astype(np.float32)
+
+
 def generate_proposals(scores, deltas, anchors, feat_stride, im_h, im_w, pre_nms_top_n, post_nms_top_n, nms_thresh,
                        min_size_scaled=0.0, return_pre_nms=False):
     """scores [A,H,W], deltas [4A,H,W] -> (boxes [k,4], scores [k])."""

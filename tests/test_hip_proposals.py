@@ -122,3 +122,42 @@ def test_sortedness_property(hip):
     assert float(b.min()) >= 0 and float(b[:, 2].max()) <= 1343 and float(b[:, 3].max()) <= 799
     top = torch.topk(torch.from_numpy(c).reshape(-1), 1000).values
     assert torch.equal(s.cpu(), top)
+
+
+def test_logit_input_equals_materialised_sigmoid(hip, oracle):
+    """the RPN head's sigmoid (detector.py:125) folded into the top-k.  Passing LOGITS must give exactly what
+    the reference flow gives for probabilities = sigmoid(logits): same top-k, same order (equal probabilities tie-break by
+    index even when they come from different logits), same scores, same boxes, same NMS survivors.  Cases: ordinary
+    logits, saturated logits (thousands of logits collapse onto 1.0f and its neighbours), quantised logits (exact
+    ties), and a level smaller than pre_nms_top_n (take-all path)."""
+    from detectorch_amd.utils.generate_anchors import generate_anchors
+    rs = synth.rng(3, 4242)
+    cases = []
+    for (A, H, W, stride, size, mu, sd, quant) in [(3, 200, 336, 4.0, 32.0, -2.0, 2.0, 0), (3, 100, 168, 8.0, 64.0, 14.0, 4.0, 0),
+                                                   (3, 50, 84, 16.0, 128.0, 9.0, 3.0, 8), (3, 13, 21, 64.0, 512.0, 0.0, 3.0, 0),
+                                                   (15, 50, 84, 16.0, (32, 64, 128, 256, 512), 1.0, 5.0, 0)]:
+        lg = (rs.standard_normal((2, A, H, W)) * sd + mu).astype(np.float32)
+        if quant:
+            lg = (np.round(lg * quant) / quant).astype(np.float32)
+        d = (rs.standard_normal((2, 4 * A, H, W)) * 0.2).astype(np.float32)
+        cases.append((lg, d, stride, size))
+    for (lg, d, stride, size) in cases:
+        sizes = size if isinstance(size, tuple) else (size,)
+        anchors = generate_anchors(stride=stride, sizes=sizes, aspect_ratios=(0.5, 1, 2))
+        pre = 6000 if len(sizes) > 1 else 1000
+        prob = oracle.rpn_sigmoid(lg)
+        tl, td = torch.from_numpy(lg).cuda(), torch.from_numpy(d).cuda()
+        fused = hip.generate_proposals([tl], [td], [anchors], [stride], 800, 1344, [pre], 1000, 0.7, scores_are_logits=True)
+        plain = hip.generate_proposals([torch.from_numpy(prob).cuda()], [td], [anchors], [stride], 800, 1344, [pre], 1000, 0.7)
+        fb, fs, fc, fpb, fps, fpc = [x.cpu().numpy() for x in fused]
+        pb_, ps_, pc_, ppb, pps, ppc = [x.cpu().numpy() for x in plain]
+        assert np.array_equal(fc, pc_) and np.array_equal(fpc, ppc)
+        for b in range(2):
+            n, m = int(fpc[b]), int(fc[b, 0])
+            assert np.array_equal(fps[b, :n], pps[b, :n]) and np.array_equal(fpb[b, :n], ppb[b, :n])
+            assert np.array_equal(fs[b, 0, :m], ps_[b, 0, :m]) and np.array_equal(fb[b, 0, :m], pb_[b, 0, :m])
+            # and against the CPU oracle run on the materialised probabilities
+            oa = oracle.generate_anchors(stride, sizes, (0.5, 1, 2))
+            rb, rsc, rpb, rps = oracle.generate_proposals(prob[b], d[b], oa, stride, 800, 1344, pre, 1000, 0.7, return_pre_nms=True)
+            assert n == rps.shape[0] and np.array_equal(fps[b, :n], rps) and np.array_equal(fpb[b, :n], rpb)
+            assert m == rsc.shape[0] and np.array_equal(fs[b, 0, :m], rsc) and np.array_equal(fb[b, 0, :m], rb)

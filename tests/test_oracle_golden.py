@@ -122,3 +122,17 @@ def test_mask_box_geometry_golden(oracle, M):
     g = golden("mask_geometry")
     got = np.stack([oracle.expand_box_int(b, M) for b in g["ref_boxes"]])
     assert np.array_equal(got, g["exp_int_M%d" % M])
+
+
+def test_rpn_sigmoid_restatement_vs_torch(oracle):
+    """oracle.rpn_sigmoid (correctly rounded) vs the reference's F.sigmoid on float32 (detector.py:125, torch CPU here):
+    never more than 2 ulp apart, monotone, saturating to exactly 1.0f / 0.0f where torch does."""
+    import torch
+    x = (np.random.RandomState(11).standard_normal(400000) * 7).astype(np.float32)
+    a = oracle.rpn_sigmoid(x)
+    b = torch.sigmoid(torch.from_numpy(x)).numpy()
+    ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 2
+    xs = np.sort(x)
+    assert (np.diff(oracle.rpn_sigmoid(xs)) >= 0).all()
+    assert oracle.rpn_sigmoid(np.float32(40.0)) == 1.0 and oracle.rpn_sigmoid(np.float32(-120.0)) == 0.0

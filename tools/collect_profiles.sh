@@ -9,8 +9,12 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 CMD="python bench.py --steps 5 --warmup 2 --batch 8 --eager --no-cpu-baseline"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- $CMD > $OUT/stats.log 2>&1 < /dev/null
-timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o fetch -- $CMD > $OUT/fetch.log 2>&1 < /dev/null
-timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o write -- $CMD > $OUT/write.log 2>&1 < /dev/null
+# HBM-side traffic from the L2's fabric (EA) request counters, one counter group per run.  FETCH_SIZE itself is NOT used:
+# on gfx950 its expression prices every read request at 64 B (TCC_BUBBLE reads 0) while almost all requests are 128 B
+# (MI355X_MICROARCH.md, HBM section: "reports exactly 1/2"); the per-size request counters give the bytes directly:
+#   read bytes  = 32*RDREQ_32B + 64*RDREQ_64B + 128*RDREQ_128B        write bytes = 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B)
+timeout 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d $OUT -o fetch -- $CMD > $OUT/fetch.log 2>&1 < /dev/null
+timeout 200 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $OUT -o write -- $CMD > $OUT/write.log 2>&1 < /dev/null
 python - <<PY
 import csv, json, collections
 out = "$OUT"
@@ -20,14 +24,19 @@ with open(out + "/kernel_stats.csv", "w", newline="") as f:
     w.writerow(rows[0])
     for r in rows[1:]:
         w.writerow([r[0] if len(r[0]) <= 110 else r[0][:107] + "..."] + r[1:])
-res = {}
+raw = collections.defaultdict(lambda: collections.defaultdict(list))      # grid -> counter -> values
 for name in ("fetch", "write"):
-    per = collections.defaultdict(list)
     for r in csv.DictReader(open(out + "/%s_counter_collection.csv" % name)):
         if "roi_align" in r["Kernel_Name"]:
-            per[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
-    res[name] = {str(g): sum(v) / len(v) for g, v in per.items()}
+            raw[int(r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for g, cs in raw.items():
+    a = {k: sum(v) / len(v) for k, v in cs.items()}
+    rd = 32 * a.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * a.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * a.get("TCC_EA0_RDREQ_128B_sum", 0)
+    w64 = a.get("TCC_EA0_WRREQ_64B_sum", 0)
+    wr = 64 * w64 + 32 * (a.get("TCC_EA0_WRREQ_sum", 0) - w64)
+    res[str(g)] = {"read_bytes": rd, "write_bytes": wr, "counters": a}
 json.dump(res, open(out + "/traffic.json", "w"), indent=1)
-print(json.dumps(res))
+print(json.dumps({g: {"read_GB": v["read_bytes"] / 1e9, "write_GB": v["write_bytes"] / 1e9} for g, v in res.items()}))
 PY
 head -12 $OUT/kernel_stats.csv | cut -c1-200
