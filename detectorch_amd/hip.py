@@ -81,6 +81,8 @@ def lib():
     L.dtc_postprocess_detections.restype = i
     L.dtc_mask_paste.argtypes = [p, p, i, i, p, p, p, i, i, f, i, p, ll, p, p, p, p, p]
     L.dtc_mask_paste.restype = i
+    L.dtc_mask_rle.argtypes = [p, ll, p, p, p, p, i, i, p, i, p, p, i, p, p]
+    L.dtc_mask_rle.restype = i
     L.dtc_soft_nms.argtypes = [p, i, f, f, f, i, p, p, p, p]
     L.dtc_soft_nms.restype = i
     L.dtc_bbox_transform.argtypes = [p, p, i, i, f, f, f, f, i, f, f, p, p]
@@ -362,6 +364,25 @@ def mask_paste(masks, dets, det_count, im_size, M, per_image_capacity, mask_inde
                                   out["boxes"].data_ptr(), out["rects"].data_ptr(), out["offsets"].data_ptr(),
                                   out["bytes"].data_ptr(), stream_ptr(dev))
     check(rc, "dtc_mask_paste")
+    return out
+
+
+def mask_rle(paste, det_count, im_size, runs_stride=4096, str_stride=8192):
+    """dtc_mask_rle on the dict returned by mask_paste -> dict(counts uint32 [B,D,runs_stride], n_runs int32 [B,D],
+    str uint8 [B,D,str_stride], str_len int32 [B,D]).  Negative n_runs / str_len: that detection did not fit."""
+    crops, rects, offs = paste["crops"], paste["rects"], paste["offsets"]
+    dev = _require_cuda(crops, rects, offs, det_count, im_size)
+    B, D = rects.shape[0], rects.shape[1]
+    out = dict(counts=torch.empty((B, D, int(runs_stride)), dtype=torch.int32, device=dev),
+               n_runs=torch.zeros((B, D), dtype=torch.int32, device=dev),
+               str=torch.empty((B, D, int(str_stride)), dtype=torch.uint8, device=dev),
+               str_len=torch.zeros((B, D), dtype=torch.int32, device=dev))
+    with torch.cuda.device(dev):
+        rc = lib().dtc_mask_rle(crops.data_ptr(), int(crops.shape[1]), rects.data_ptr(), offs.data_ptr(),
+                                det_count.data_ptr(), im_size.to(torch.float32).contiguous().data_ptr(), B, D,
+                                out["counts"].data_ptr(), int(runs_stride), out["n_runs"].data_ptr(),
+                                out["str"].data_ptr(), int(str_stride), out["str_len"].data_ptr(), stream_ptr(dev))
+    check(rc, "dtc_mask_rle")
     return out
 
 

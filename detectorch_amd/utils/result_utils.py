@@ -3,7 +3,7 @@ the arithmetic done by the HIP kernels (detectorch_amd/csrc/detections.hip, nms.
 
     postprocess_output              result_utils.py:76-94
     box_results_with_nms_and_limit  result_utils.py:96-168   (hard NMS and Soft-NMS; bbox voting is not on the hot path)
-    segm_results                    result_utils.py:170-228  (RLE: pycocotools if importable, else the numpy encoder below)
+    segm_results                    result_utils.py:170-228  (RLE on the device: dtc_mask_rle)
     empty_results / extend_results  result_utils.py:32-60
 """
 import numpy as np
@@ -106,7 +106,7 @@ def box_results_with_nms_and_limit(scores, boxes, num_classes=81, score_thresh=0
     return im_results[:, -1], im_results[:, :-1], cls_boxes
 
 
-# ---- COCO RLE (the wire format pycocotools.mask.encode produces); used only when pycocotools is not importable -------
+# ---- COCO RLE of a dense host mask (utility for callers that hold numpy masks; segm_results encodes on the device) ----
 def _rle_counts_to_string(cnts):
     out = []
     for i, c in enumerate(cnts):
@@ -156,23 +156,23 @@ def segm_results(cls_boxes, masks, ref_boxes, im_h, im_w, num_classes=81, M=14, 
                          torch.tensor([[float(im_h), float(im_w)]], device=dev), M, cap,
                          mask_index=torch.arange(D, dtype=torch.int32, device=dev).reshape(1, D), thresh=thresh_binarize,
                          cls_specific=cls_specific_mask)
-    nbytes = int(out["bytes"][0].item())
-    crops = out["crops"][0, :nbytes].cpu().numpy()
-    rects = out["rects"][0].cpu().numpy()
-    offs = out["offsets"][0].cpu().numpy()
-    try:
-        import pycocotools.mask as mask_util
-    except ImportError:
-        mask_util = None
+    # COCO RLE on the device (dtc_mask_rle): only the count strings cross PCIe.  If a mask has more runs than the first
+    # guess holds (pathological noise), the kernel reports the sizes it needs and is re-run once with those.
+    dcount = torch.tensor([D], dtype=torch.int32, device=dev)
+    imsz = torch.tensor([[float(im_h), float(im_w)]], device=dev)
+    runs_stride, str_stride = 2 * int(im_w) + 8, 4 * int(im_w) + 64
+    for _ in range(3):
+        rle = hip.mask_rle(out, dcount, imsz, runs_stride=runs_stride, str_stride=str_stride)
+        nrun = rle["n_runs"][0].cpu().numpy()
+        slen = rle["str_len"][0].cpu().numpy()
+        if nrun.min() >= 0 and slen.min() >= 0:
+            break
+        runs_stride = max(runs_stride, int(-nrun.min()) + 8)
+        str_stride = max(str_stride, int(-slen.min()) + 8, 7 * runs_stride)
+    else:
+        raise RuntimeError("dtc_mask_rle: buffers still too small")
+    sbuf = rle["str"][0, :, :max(int(slen.max()), 1)].cpu().numpy()
     for d in range(D):
-        x0, y0, x1, y1 = rects[d]
-        im_mask = np.zeros((int(im_h), int(im_w)), dtype=np.uint8)
-        if x1 > x0 and y1 > y0:
-            im_mask[y0:y1, x0:x1] = crops[offs[d]:offs[d] + (x1 - x0) * (y1 - y0)].reshape(y1 - y0, x1 - x0)
-        if mask_util is not None:
-            rle = mask_util.encode(np.array(im_mask[:, :, np.newaxis], order='F'))[0]
-            rle['counts'] = rle['counts'].decode()
-        else:
-            rle = rle_encode(im_mask)
-        cls_segms[int(cls_of[d])].append(rle)
+        cls_segms[int(cls_of[d])].append({'size': [int(im_h), int(im_w)],
+                                          'counts': sbuf[d, :slen[d]].tobytes().decode('ascii')})
     return cls_segms

@@ -208,6 +208,18 @@ int dtc_mask_paste(const float* masks, const int32_t* mask_index, int n_cls, int
                    int cls_specific_mask, uint8_t* crops, long long per_image_capacity, int32_t* mask_boxes,
                    int32_t* mask_rects, long long* mask_offsets, long long* mask_bytes, dtc_stream_t stream);
 
+/* COCO RLE of every pasted mask, on the device: what `mask_util.encode(np.array(im_mask[:, :, np.newaxis], order='F'))`
+ * returns at lib/utils/result_utils.py:217-220 (pycocotools rleEncode + rleToString), computed from dtc_mask_paste's
+ * crops / mask_rects / mask_offsets without materialising the (im_h, im_w) frame.  Per detection (b, d):
+ *   rle_counts uint32 [B,max_out,runs_stride]  run lengths (column-major, first run = zeros), rle_n_runs int32 [B,max_out]
+ *   rle_str    uint8  [B,max_out,str_stride]   the compressed "counts" string (ASCII, no terminator), rle_str_len int32
+ * A detection whose runs (string) do not fit gets rle_n_runs = -(runs needed) (rle_str_len = -(bytes needed)) and no
+ * valid data: re-run with larger strides or encode that one on the host.  d >= det_count[b]: 0 / 0. */
+int dtc_mask_rle(const uint8_t* crops, long long per_image_capacity, const int32_t* mask_rects,
+                 const long long* mask_offsets, const int32_t* det_count, const float* im_size, int batch, int max_out,
+                 uint32_t* rle_counts, int runs_stride, int32_t* rle_n_runs, uint8_t* rle_str, int str_stride,
+                 int32_t* rle_str_len, dtc_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * A6  Soft-NMS  and  A4 (numpy flavour) box decode
  * --------------------------------------------------------------------------------------------------------------- */

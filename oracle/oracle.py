@@ -52,6 +52,10 @@ def lib():
         _LIB.orc_expand_box_int.restype = None
         _LIB.orc_mask_resize_binarize.argtypes = [p, i, p, f, p, p]
         _LIB.orc_mask_resize_binarize.restype = i
+        _LIB.orc_rle_runs.argtypes = [p, i, i, p]
+        _LIB.orc_rle_runs.restype = C.c_longlong
+        _LIB.orc_rle_string.argtypes = [p, C.c_longlong, p]
+        _LIB.orc_rle_string.restype = C.c_longlong
     return _LIB
 
 
@@ -213,3 +217,15 @@ def mask_resize_binarize(mask, ref_box, thresh=0.5):
                                    box.ctypes.data, crop.ctypes.data)
     w, h = max(box[2] - box[0] + 1, 1), max(box[3] - box[1] + 1, 1)
     return box, crop.reshape(h, w)
+
+
+def rle_encode(mask):
+    """mask [h,w] uint8 -> (runs uint32 [n], counts str): the COCO RLE of result_utils.py:217-220 (pycocotools restated)."""
+    mask = np.ascontiguousarray(mask, np.uint8)
+    h, w = mask.shape
+    n = lib().orc_rle_runs(mask.ctypes.data, h, w, None)
+    runs = np.zeros(n, np.uint32)
+    lib().orc_rle_runs(mask.ctypes.data, h, w, runs.ctypes.data)
+    buf = np.zeros(7 * n, np.uint8)
+    m = lib().orc_rle_string(runs.ctypes.data, n, buf.ctypes.data)
+    return runs, buf[:m].tobytes().decode("ascii")

@@ -223,3 +223,83 @@ def test_zero_detections_everywhere(hip, oracle):
     assert int(out["bytes"][0]) == 0
     segms = result_utils.segm_results(cb, torch.zeros((0, 81, 28, 28), device="cuda"), bx, 500, 833, M=28)
     assert all(len(s) == 0 for s in segms)
+
+
+def _rle_case(hip, oracle, frames_rects, im_h, im_w, runs_stride=4096, str_stride=8192):
+    """frames_rects: list of (frame uint8 [im_h,im_w] that is zero outside rect, rect (x0,y0,x1,y1)).  Packs the crops the
+    way dtc_mask_paste does and runs dtc_mask_rle."""
+    D = len(frames_rects)
+    crops, offs, rects = [], [], []
+    pos = 0
+    for fr, (x0, y0, x1, y1) in frames_rects:
+        c = np.ascontiguousarray(fr[y0:y1, x0:x1]).reshape(-1) if (x1 > x0 and y1 > y0) else np.zeros(0, np.uint8)
+        offs.append(pos); rects.append([x0, y0, x1, y1]); crops.append(c); pos += c.size
+    buf = np.concatenate(crops + [np.zeros(1, np.uint8)])
+    paste = dict(crops=torch.from_numpy(buf).cuda().reshape(1, -1),
+                 rects=torch.tensor(rects, dtype=torch.int32, device="cuda").reshape(1, D, 4),
+                 offsets=torch.tensor(offs, dtype=torch.int64, device="cuda").reshape(1, D))
+    out = hip.mask_rle(paste, torch.tensor([D], dtype=torch.int32, device="cuda"),
+                       torch.tensor([[float(im_h), float(im_w)]], device="cuda"), runs_stride, str_stride)
+    return {k: v[0].cpu().numpy() for k, v in out.items()}
+
+
+def test_device_rle_vs_oracle(hip, oracle):
+    """dtc_mask_rle == the restated pycocotools encoder (oracle/oracle.c: orc_rle_runs / orc_rle_string) on the
+    pasted frame -- run lengths and the compressed string, bit for bit.  Cases: random densities, blobs, crops touching
+    every frame edge (incl. full-height crops whose columns are contiguous in the column-major walk, and a set pixel in the
+    frame's last position), empty rectangles, an all-ones frame, and the buffer-too-small report."""
+    rs = synth.rng(9, 1)
+    im_h, im_w = 61, 83
+    cases = []
+    for t in range(24):
+        x0, y0 = rs.randint(0, im_w - 1), rs.randint(0, im_h - 1)
+        x1, y1 = rs.randint(x0 + 1, im_w + 1), rs.randint(y0 + 1, im_h + 1)
+        if t % 6 == 0: y0, y1 = 0, im_h                       # full-height crop
+        if t % 6 == 1: x1, y1 = im_w, im_h                    # touches the last frame pixel
+        if t % 6 == 2: x0, y0 = 0, 0
+        fr = np.zeros((im_h, im_w), np.uint8)
+        dens = rs.rand()
+        fr[y0:y1, x0:x1] = (rs.rand(y1 - y0, x1 - x0) < dens).astype(np.uint8)
+        if t % 6 == 1: fr[im_h - 1, im_w - 1] = 1
+        if t % 6 == 3:                                         # solid blob
+            fr[:] = 0; fr[y0:y1, x0:x1] = 1
+        cases.append((fr, (x0, y0, x1, y1)))
+    cases.append((np.zeros((im_h, im_w), np.uint8), (10, 10, 10, 20)))      # empty rectangle
+    cases.append((np.ones((im_h, im_w), np.uint8), (0, 0, im_w, im_h)))     # everything set: runs [0, N]
+    out = _rle_case(hip, oracle, cases, im_h, im_w)
+    for d, (fr, _) in enumerate(cases):
+        runs, s = oracle.rle_encode(fr)
+        n = int(out["n_runs"][d])
+        assert n == len(runs), d
+        assert np.array_equal(out["counts"][d, :n].view(np.uint32), runs), d
+        assert out["str"][d, :out["str_len"][d]].tobytes().decode("ascii") == s, d
+    # a checkerboard needs h*w runs: reported as -(needed), nothing valid written
+    cb = (np.indices((im_h, im_w)).sum(0) % 2).astype(np.uint8)
+    out = _rle_case(hip, oracle, [(cb, (0, 0, im_w, im_h))], im_h, im_w, runs_stride=256, str_stride=256)
+    assert out["n_runs"][0] == -len(oracle.rle_encode(cb)[0]) and out["str_len"][0] < 0
+    out = _rle_case(hip, oracle, [(cb, (0, 0, im_w, im_h))], im_h, im_w, runs_stride=im_h * im_w + 8, str_stride=7 * im_h * im_w)
+    runs, s = oracle.rle_encode(cb)
+    assert out["n_runs"][0] == len(runs) and out["str"][0, :out["str_len"][0]].tobytes().decode("ascii") == s
+
+
+def test_device_rle_full_size_property(hip, oracle):
+    """BASELINE-size frame (800x1333), large blobs: decode(encode) == frame via the run lengths (size-independent property:
+    runs alternate 0/1, sum to h*w) and equality with the oracle."""
+    rs = synth.rng(9, 2)
+    im_h, im_w = 800, 1333
+    cases = []
+    for t in range(6):
+        x0, y0 = rs.randint(0, im_w - 300), rs.randint(0, im_h - 300)
+        x1, y1 = x0 + rs.randint(40, 300), y0 + rs.randint(40, 300)
+        yy, xx = np.mgrid[y0:y1, x0:x1]
+        blob = (((xx - (x0 + x1) / 2) / ((x1 - x0) / 2)) ** 2 + ((yy - (y0 + y1) / 2) / ((y1 - y0) / 2)) ** 2 < 1).astype(np.uint8)
+        fr = np.zeros((im_h, im_w), np.uint8); fr[y0:y1, x0:x1] = blob
+        cases.append((fr, (x0, y0, x1, y1)))
+    out = _rle_case(hip, oracle, cases, im_h, im_w)
+    for d, (fr, _) in enumerate(cases):
+        n = int(out["n_runs"][d])
+        runs = out["counts"][d, :n].view(np.uint32).astype(np.int64)
+        assert runs.sum() == im_h * im_w
+        dec = np.repeat(np.arange(n) % 2, runs).astype(np.uint8).reshape(im_w, im_h).T
+        assert np.array_equal(dec, fr)
+        assert out["str"][d, :out["str_len"][d]].tobytes().decode("ascii") == oracle.rle_encode(fr)[1]

@@ -136,3 +136,22 @@ def test_rpn_sigmoid_restatement_vs_torch(oracle):
     xs = np.sort(x)
     assert (np.diff(oracle.rpn_sigmoid(xs)) >= 0).all()
     assert oracle.rpn_sigmoid(np.float32(40.0)) == 1.0 and oracle.rpn_sigmoid(np.float32(-120.0)) == 0.0
+
+
+def test_rle_restatement_known_answers(oracle):
+    """COCO RLE (third-party pycocotools, absent: parity unpinned) -- known answers derived by hand from the format
+    definition: column-major runs starting with zeros; 5-bit groups + '0', deltas vs count[i-2] from the 4th count on."""
+    m = np.array([[0, 0, 1, 1, 0], [0, 1, 1, 1, 0], [0, 1, 1, 0, 0], [0, 0, 0, 0, 0]], np.uint8)
+    runs, s = oracle.rle_encode(m)
+    assert runs.tolist() == [5, 2, 1, 3, 1, 2, 6]          # columns 0000|0110|1110|1100|0000 read top to bottom
+    # counts 5,2,1 verbatim; then deltas vs count[i-2]: 3-2=1, 1-1=0, 2-3=-1 (all-ones group 0x1f -> 'O'), 6-1=5
+    assert s == "52110O5"
+    assert oracle.rle_encode(np.ones((2, 2), np.uint8)) [1] == "04"
+    assert oracle.rle_encode(np.zeros((3, 5), np.uint8))[1] == "?"          # single run of 15 -> chr(15 + 48)
+    big = np.zeros((40, 50), np.uint8); big[5:30, 10:12] = 1              # runs 405,25,15,25,1530: multi-group counts
+    runs, s = oracle.rle_encode(big)
+    assert runs.tolist() == [405, 25, 15, 25, 1530]
+    # 405 = 0b01100_10101 -> groups 21|0x20, 12 -> 'e','<' ; 25 -> 25|0x20, 0 (bit 4 set needs a sign group) -> 'i','0'
+    assert s[:4] == "e<i0"
+    from detectorch_amd.utils.result_utils import rle_encode
+    assert rle_encode(big)["counts"] == s and rle_encode(m)["counts"] == "52110O5"
