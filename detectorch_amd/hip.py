@@ -83,6 +83,10 @@ def lib():
     L.dtc_mask_paste.restype = i
     L.dtc_mask_rle.argtypes = [p, ll, p, p, p, p, i, i, p, i, p, p, i, p, p]
     L.dtc_mask_rle.restype = i
+    L.dtc_bbox_overlaps.argtypes = [p, i, i, p, i, i, p, p]
+    L.dtc_bbox_overlaps.restype = i
+    L.dtc_box_voting.argtypes = [p, i, p, i, f, p, p, p]
+    L.dtc_box_voting.restype = i
     L.dtc_soft_nms.argtypes = [p, i, f, f, f, i, p, p, p, p]
     L.dtc_soft_nms.restype = i
     L.dtc_bbox_transform.argtypes = [p, p, i, i, f, f, f, f, i, f, f, p, p]
@@ -384,6 +388,33 @@ def mask_rle(paste, det_count, im_size, runs_stride=4096, str_stride=8192):
                                 out["str"].data_ptr(), int(str_stride), out["str_len"].data_ptr(), stream_ptr(dev))
     check(rc, "dtc_mask_rle")
     return out
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """dtc_bbox_overlaps: [N,>=4], [K,>=4] float32 CUDA -> [N,K] float32 (cython_bbox.pyx:32-72)."""
+    dev = _require_cuda(boxes, query_boxes)
+    boxes, query_boxes = boxes.contiguous(), query_boxes.contiguous()
+    n, k = boxes.shape[0], query_boxes.shape[0]
+    out = torch.zeros((n, k), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().dtc_bbox_overlaps(boxes.data_ptr(), n, boxes.shape[1] if n else 4, query_boxes.data_ptr(), k,
+                                     query_boxes.shape[1] if k else 4, out.data_ptr(), stream_ptr(dev))
+    check(rc, "dtc_bbox_overlaps")
+    return out
+
+
+def box_voting(top_dets, all_dets, thresh):
+    """dtc_box_voting ('ID' scoring): [T,5], [A,5] float32 CUDA -> ([T,5], n_voters int32 [T])."""
+    dev = _require_cuda(top_dets, all_dets)
+    top_dets, all_dets = top_dets.contiguous(), all_dets.contiguous()
+    t, a = top_dets.shape[0], all_dets.shape[0]
+    out = torch.empty((t, 5), dtype=torch.float32, device=dev)
+    nv = torch.zeros((max(t, 1),), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().dtc_box_voting(top_dets.data_ptr(), t, all_dets.data_ptr(), a, float(thresh), out.data_ptr(),
+                                  nv.data_ptr(), stream_ptr(dev))
+    check(rc, "dtc_box_voting")
+    return out, nv[:t]
 
 
 def soft_nms(dets, sigma, overlap_thresh, score_thresh, method):

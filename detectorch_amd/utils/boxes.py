@@ -4,6 +4,8 @@ same names and numpy-in / numpy-out conventions, computed by the HIP kernels (de
     nms              boxes.py:332-336   -> dtc_nms            (cython_nms.pyx:37-87)
     soft_nms         boxes.py:339-356   -> dtc_soft_nms       (cython_nms.pyx:98-203)
     bbox_transform   boxes.py:168-208   -> dtc_bbox_transform
+    bbox_overlaps    boxes.py:53-69 (cython_bbox.pyx:32-72) -> dtc_bbox_overlaps
+    box_voting       boxes.py:280-329   -> dtc_box_voting (+ host statistics for the non-'ID' scoring methods)
     clip_tiled_boxes boxes.py:150-165
     expand_boxes     boxes.py:245-261 ; boxes_area boxes.py:75-81  (trivial host numpy, identical arithmetic)
 
@@ -83,3 +85,53 @@ def expand_boxes(boxes, scale):
     boxes_exp[:, 1] = y_c - h_half
     boxes_exp[:, 3] = y_c + h_half
     return boxes_exp
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """IoU matrix [N,K] float32 of boxes [N,4] vs query_boxes [K,4] (cython_bbox.bbox_overlaps, cython_bbox.pyx:32-72)."""
+    b = np.ascontiguousarray(boxes, dtype=np.float32)
+    q = np.ascontiguousarray(query_boxes, dtype=np.float32)
+    if b.shape[0] == 0 or q.shape[0] == 0:
+        return np.zeros((b.shape[0], q.shape[0]), dtype=np.float32)
+    dev = _dev()
+    return hip.bbox_overlaps(torch.from_numpy(b).to(dev), torch.from_numpy(q).to(dev)).cpu().numpy()
+
+
+def box_voting(top_dets, all_dets, thresh, scoring_method='ID', beta=1.0):
+    """Bounding-box voting (boxes.py:280-329): every row of top_dets [N,5] gets its box replaced by the score-weighted
+    mean of the all_dets [M,5] that overlap it by IoU >= thresh (device: dtc_box_voting).  scoring_method other than 'ID'
+    also rewrites the score column from the voters' scores -- small host statistics over the device IoU matrix."""
+    methods = ('ID', 'TEMP_AVG', 'AVG', 'IOU_AVG', 'GENERALIZED_AVG', 'QUASI_SUM')
+    if scoring_method not in methods:
+        raise NotImplementedError('Unknown scoring method {}'.format(scoring_method))       # boxes.py:324-327
+    top = np.ascontiguousarray(top_dets, dtype=np.float32)
+    alld = np.ascontiguousarray(all_dets, dtype=np.float32)
+    if top.shape[0] == 0:
+        return top.copy()
+    dev = _dev()
+    t_top, t_all = torch.from_numpy(top).to(dev), torch.from_numpy(alld).to(dev)
+    voted, n_voters = hip.box_voting(t_top, t_all, np.float32(thresh))
+    if int(n_voters.min().item()) == 0:
+        raise ZeroDivisionError("Weights sum to zero, can't be normalized")                 # what np.average raises at :295
+    out = voted.cpu().numpy()
+    if scoring_method == 'ID':
+        return out
+    iou = hip.bbox_overlaps(t_top[:, :4].contiguous(), t_all[:, :4].contiguous()).cpu().numpy()
+    scores_all = alld[:, 4]
+    for k in range(out.shape[0]):
+        sel = np.where(iou[k] >= thresh)[0]
+        ws = scores_all[sel]
+        if scoring_method == 'AVG':                                                          # :311-313
+            out[k, 4] = ws.mean()
+        elif scoring_method == 'IOU_AVG':                                                    # :314-318
+            out[k, 4] = np.average(ws, weights=iou[k, sel])
+        elif scoring_method == 'GENERALIZED_AVG':                                            # :319-321
+            out[k, 4] = np.mean(ws ** beta) ** (1.0 / beta)
+        elif scoring_method == 'QUASI_SUM':                                                  # :322-323
+            out[k, 4] = ws.sum() / float(len(ws)) ** beta
+        else:                                                                                # 'TEMP_AVG' :300-310
+            two = np.vstack((ws, 1.0 - ws))
+            logit = np.log(two / np.max(two, axis=0))
+            soft = np.exp(logit / beta)
+            out[k, 4] = (soft / np.sum(soft, axis=0))[0].mean()
+    return out

@@ -2,7 +2,7 @@
 the arithmetic done by the HIP kernels (detectorch_amd/csrc/detections.hip, nms.hip, mask_paste.hip).
 
     postprocess_output              result_utils.py:76-94
-    box_results_with_nms_and_limit  result_utils.py:96-168   (hard NMS and Soft-NMS; bbox voting is not on the hot path)
+    box_results_with_nms_and_limit  result_utils.py:96-168   (hard NMS, Soft-NMS, optional bbox voting)
     segm_results                    result_utils.py:170-228  (RLE on the device: dtc_mask_rle)
     empty_results / extend_results  result_utils.py:32-60
 """
@@ -80,8 +80,6 @@ def box_results_with_nms_and_limit(scores, boxes, num_classes=81, score_thresh=0
                                    do_soft_nms=False, soft_nms_sigma=0.5, soft_nms_method='linear', do_bbox_vote=False,
                                    bbox_vote_thresh=0.8, bbox_vote_method='ID', max_detections_per_img=100):
     """result_utils.py:96-168 on already decoded+clipped boxes [R,4*num_classes] (numpy in / numpy out)."""
-    if do_bbox_vote:
-        raise NotImplementedError("bbox voting (lib/utils/boxes.py:280-329) is off by default and out of the hot-path scope")
     scores = np.ascontiguousarray(scores, np.float32)
     boxes = np.ascontiguousarray(boxes, np.float32)
     cls_boxes = [[] for _ in range(num_classes)]
@@ -94,6 +92,8 @@ def box_results_with_nms_and_limit(scores, boxes, num_classes=81, score_thresh=0
         else:
             keep = box_utils.nms(dets_j, overlap_thresh)
             nms_dets = dets_j[keep, :]
+        if do_bbox_vote:                                       # result_utils.py:147-153
+            nms_dets = box_utils.box_voting(nms_dets, dets_j, bbox_vote_thresh, scoring_method=bbox_vote_method)
         cls_boxes[j] = nms_dets
     if max_detections_per_img > 0:
         image_scores = np.hstack([cls_boxes[j][:, -1] for j in range(1, num_classes)])

@@ -221,6 +221,23 @@ int dtc_mask_rle(const uint8_t* crops, long long per_image_capacity, const int32
                  int32_t* rle_str_len, dtc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * (f)-4  bbox_overlaps / box_voting (the optional bbox-vote branch of the detection post-processing)
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* Drop-in for cython_bbox.bbox_overlaps(boxes, query_boxes)  lib/utils_cython/cython_bbox.pyx:32-72:
+ * boxes float32 [n, box_cols>=4], query_boxes [k, query_cols>=4] (first four columns x1,y1,x2,y2) -> overlaps [n,k]. */
+int dtc_bbox_overlaps(const float* boxes, int n, int box_cols, const float* query_boxes, int k, int query_cols,
+                      float* overlaps, dtc_stream_t stream);
+
+/* box_voting(top_dets, all_dets, thresh, scoring_method='ID')  lib/utils/boxes.py:280-329: top_dets [n_top,5],
+ * all_dets [n_all,5] (x1,y1,x2,y2,score), n_all <= 8192 -> top_dets_out [n_top,5] with the boxes replaced by the
+ * score-weighted average of the all_dets whose IoU with the top det is >= thresh (numpy's float32 evaluation order);
+ * n_voters int32 [n_top] (optional) = number of voters (0: row copied unchanged; cannot happen for the reference's
+ * call, where every top det is one of all_dets). */
+int dtc_box_voting(const float* top_dets, int n_top, const float* all_dets, int n_all, float thresh,
+                   float* top_dets_out, int32_t* n_voters, dtc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * A6  Soft-NMS  and  A4 (numpy flavour) box decode
  * --------------------------------------------------------------------------------------------------------------- */
 

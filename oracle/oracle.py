@@ -52,6 +52,10 @@ def lib():
         _LIB.orc_expand_box_int.restype = None
         _LIB.orc_mask_resize_binarize.argtypes = [p, i, p, f, p, p]
         _LIB.orc_mask_resize_binarize.restype = i
+        _LIB.orc_bbox_overlaps.argtypes = [p, i, p, i, p]
+        _LIB.orc_bbox_overlaps.restype = None
+        _LIB.orc_box_voting.argtypes = [p, i, p, i, f, p]
+        _LIB.orc_box_voting.restype = i
         _LIB.orc_rle_runs.argtypes = [p, i, i, p]
         _LIB.orc_rle_runs.restype = C.c_longlong
         _LIB.orc_rle_string.argtypes = [p, C.c_longlong, p]
@@ -229,3 +233,19 @@ def rle_encode(mask):
     buf = np.zeros(7 * n, np.uint8)
     m = lib().orc_rle_string(runs.ctypes.data, n, buf.ctypes.data)
     return runs, buf[:m].tobytes().decode("ascii")
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """cython_bbox.bbox_overlaps (cython_bbox.pyx:32-72): [N,4] x [K,4] -> [N,K] float32."""
+    b, q = _f32(boxes), _f32(query_boxes)
+    out = np.zeros((b.shape[0], q.shape[0]), np.float32)
+    lib().orc_bbox_overlaps(b.ctypes.data, b.shape[0], q.ctypes.data, q.shape[0], out.ctypes.data)
+    return out
+
+
+def box_voting(top_dets, all_dets, thresh):
+    """boxes.py:280-329 with scoring_method='ID': [T,5], [A,5] -> [T,5]."""
+    t, a = _f32(top_dets), _f32(all_dets)
+    out = np.zeros_like(t)
+    lib().orc_box_voting(t.ctypes.data, t.shape[0], a.ctypes.data, a.shape[0], float(np.float32(thresh)), out.ctypes.data)
+    return out

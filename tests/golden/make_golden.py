@@ -31,9 +31,36 @@ def save(name, **arrs):
     print("%-28s %7.1f KB  %s" % (name, os.path.getsize(path) / 1024.0, sorted(arrs)))
 
 
+def bbox_vote(ns):
+    """(f)-4: cython_bbox.bbox_overlaps (cython_bbox.pyx:32) and boxes.box_voting (boxes.py:280) run by the reference."""
+    rs = synth.rng(7, 0)
+    n = 600
+    centres = synth.make_rois(rs, 12, im_h=500, im_w=833, min_side=20, max_side=300)
+    a = centres[rs.randint(0, 12, n)] + rs.standard_normal((n, 4)).astype(np.float32) * 4
+    a[:, 2:] = np.maximum(a[:, 2:], a[:, :2] + 1)
+    all_dets = np.ascontiguousarray(np.hstack([a, rs.uniform(0.05, 1, (n, 1))]), np.float32)
+    top = np.ascontiguousarray(all_dets[rs.choice(n, 40, replace=False)])
+    q = synth.make_rois(rs, 37, im_h=500, im_w=833, min_side=4, max_side=500)
+    arrs = dict(all_dets=all_dets, top_dets=top, query=q,
+                overlaps=ns.cython_bbox.bbox_overlaps(np.ascontiguousarray(all_dets[:, :4]), q),
+                overlaps_top=ns.cython_bbox.bbox_overlaps(np.ascontiguousarray(top[:, :4]), np.ascontiguousarray(all_dets[:, :4])))
+    for m in ('ID', 'TEMP_AVG', 'AVG', 'IOU_AVG', 'GENERALIZED_AVG', 'QUASI_SUM'):
+        for beta in (1.0, 0.5):
+            arrs["vote_%s_b%d" % (m, int(beta * 10))] = ns.boxes.box_voting(top, all_dets, 0.6, scoring_method=m, beta=beta)
+    # the voting branch of box_results_with_nms_and_limit on the postprocess fixture's inputs
+    g = np.load(os.path.join(HERE, "postprocess.npz"))
+    sc, bx, cb = ns.result_utils.box_results_with_nms_and_limit(g["cls"], g["pred_clipped"].copy(), do_bbox_vote=True,
+                                                                bbox_vote_thresh=0.8)
+    arrs["pp_vote_scores"], arrs["pp_vote_boxes"] = sc, bx
+    arrs["pp_vote_cls_id"] = np.concatenate([np.full(len(cb[j]), j, np.int32) for j in range(1, 81)])
+    save("bbox_vote", **arrs)
+
+
 def main():
     ns = rh.load_reference()
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bbox_vote":     # add one fixture without rewriting the others
+        return bbox_vote(ns)
 
     # ---- A2 anchors (generate_anchors.py:54) -------------------------------------------------------------------
     arrs = {}
@@ -170,6 +197,7 @@ def main():
     for M in (14, 28):
         arrs["exp_int_M%d" % M] = ns.boxes.expand_boxes(ref_boxes, (M + 2.0) / M).astype(np.int32)
     save("mask_geometry", **arrs)
+    bbox_vote(ns)
 
 
 if __name__ == "__main__":

@@ -155,3 +155,13 @@ def test_rle_restatement_known_answers(oracle):
     assert s[:4] == "e<i0"
     from detectorch_amd.utils.result_utils import rle_encode
     assert rle_encode(big)["counts"] == s and rle_encode(m)["counts"] == "52110O5"
+
+
+def test_bbox_overlaps_and_voting_golden(oracle):
+    """oracle.bbox_overlaps / box_voting vs the outputs of the reference's cython_bbox.bbox_overlaps and boxes.box_voting
+    (tests/golden/bbox_vote.npz), bit-exact -- this is what pins the mixed float32/double reading of cython_bbox.pyx."""
+    g = golden("bbox_vote")
+    assert np.array_equal(oracle.bbox_overlaps(g["all_dets"][:, :4], g["query"]), g["overlaps"])
+    assert np.array_equal(oracle.bbox_overlaps(g["top_dets"][:, :4], g["all_dets"][:, :4]), g["overlaps_top"])
+    assert np.array_equal(oracle.box_voting(g["top_dets"], g["all_dets"], 0.6), g["vote_ID_b10"])
+    assert (g["overlaps_top"] >= 0.6).sum(1).max() > 8          # the pairwise-sum branch (>= 8 voters) is exercised

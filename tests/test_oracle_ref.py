@@ -54,3 +54,21 @@ def test_soft_nms_vs_reference_cython(oracle, ref, method):
     d, k = oracle.soft_nms(dets, 0.5, 0.3, 0.001, method)
     assert np.array_equal(k, np.asarray(rk, np.int64))
     assert np.array_equal(d, rd)
+
+
+def test_bbox_overlaps_and_box_voting_vs_reference(oracle, ref):
+    """orc_bbox_overlaps vs the reference's own Cython build; orc_box_voting vs lib/utils/boxes.py:280 imported in place
+    (hundreds of voters per top det: numpy's pairwise float32 sum beyond 128 elements is on the path)."""
+    _, cb = ref.load_ref_cython()
+    ns = ref.load_reference()
+    rs = synth.rng(13, 0)
+    for t in range(6):
+        b = synth.make_rois(rs, 150 + 37 * t); q = synth.make_rois(rs, 90 + 11 * t)
+        assert np.array_equal(oracle.bbox_overlaps(b, q), cb.bbox_overlaps(np.ascontiguousarray(b), np.ascontiguousarray(q)))
+    base = np.array([[50, 60, 200, 220], [300, 100, 420, 300], [10, 10, 600, 400]], np.float32)
+    for t in range(4):
+        n = 400 + 300 * t
+        a = base[rs.randint(0, 3, n)] + rs.standard_normal((n, 4)).astype(np.float32) * 3
+        all_d = np.ascontiguousarray(np.hstack([a, rs.uniform(0, 1, (n, 1))]), np.float32)
+        top = np.ascontiguousarray(all_d[rs.choice(n, 10, replace=False)])
+        assert np.array_equal(oracle.box_voting(top, all_d, 0.5), ns.boxes.box_voting(top, all_d, 0.5))
