@@ -17,6 +17,12 @@ DTC_MAX_LEVELS = 8
 _ERR = {-1: "DTC_EINVAL", -2: "DTC_ELAUNCH", -3: "DTC_EWORKSPACE", -4: "DTC_EUNSUPPORTED"}
 
 
+class Image(C.Structure):
+    """struct dtc_image (include/detectorch_hip.h)"""
+    _fields_ = [("data", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32), ("dtype", C.c_int32),
+                ("row_stride", C.c_int32)]
+
+
 class RpnLevel(C.Structure):
     """struct dtc_rpn_level (include/detectorch_hip.h)"""
     _fields_ = [("cls_prob", C.c_void_p), ("bbox_pred", C.c_void_p), ("num_anchors", C.c_int32), ("height", C.c_int32),
@@ -83,6 +89,10 @@ def lib():
     L.dtc_mask_paste.restype = i
     L.dtc_mask_rle.argtypes = [p, ll, p, p, p, p, i, i, p, i, p, p, i, p, p]
     L.dtc_mask_rle.restype = i
+    L.dtc_prep_plan.argtypes = [p, p, i, i, i, i, p, p, p]
+    L.dtc_prep_plan.restype = i
+    L.dtc_prep_images.argtypes = [C.POINTER(Image), i, p, p, p, p, i, i, p]
+    L.dtc_prep_images.restype = i
     L.dtc_bbox_overlaps.argtypes = [p, i, i, p, i, i, p, p]
     L.dtc_bbox_overlaps.restype = i
     L.dtc_box_voting.argtypes = [p, i, p, i, f, p, p, p]
@@ -415,6 +425,39 @@ def box_voting(top_dets, all_dets, thresh):
                                   nv.data_ptr(), stream_ptr(dev))
     check(rc, "dtc_box_voting")
     return out, nv[:t]
+
+
+def prep_images(images, pixel_means=(122.7717, 115.9465, 102.9801), target_size=800, max_size=1333, pad_stride=32):
+    """dtc_prep_plan + dtc_prep_images: list of HWC BGR CUDA tensors (uint8 or float32, [h,w,3]) ->
+    (blob float32 [B,3,Hb,Wb] on the device, im_scales list of float, resized sizes list of (h, w))."""
+    dev = _require_cuda(*images)
+    B = len(images)
+    ims = [im if im.stride(2) == 1 and im.stride(1) == 3 else im.contiguous() for im in images]
+    hs = (C.c_int32 * B)(*[int(im.shape[0]) for im in ims])
+    ws_ = (C.c_int32 * B)(*[int(im.shape[1]) for im in ims])
+    scales = (C.c_double * B)()
+    out_hw = (C.c_int32 * (2 * B))()
+    blob_hw = (C.c_int32 * 2)()
+    check(lib().dtc_prep_plan(hs, ws_, B, int(target_size), int(max_size), int(pad_stride), scales, out_hw, blob_hw),
+          "dtc_prep_plan")
+    arr = (Image * B)()
+    for k, im in enumerate(ims):
+        if im.dtype == torch.uint8:
+            dt = 2
+        elif im.dtype == torch.float32:
+            dt = 0
+        else:
+            raise TypeError("images must be uint8 or float32")
+        if im.dim() != 3 or im.shape[2] != 3:
+            raise ValueError("images must be [h,w,3] (BGR)")
+        arr[k] = Image(im.data_ptr(), int(im.shape[0]), int(im.shape[1]), dt, int(im.stride(0)))
+    means = (C.c_double * 3)(*[float(m) for m in pixel_means])
+    blob = torch.empty((B, 3, blob_hw[0], blob_hw[1]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().dtc_prep_images(arr, B, means, scales, out_hw, blob.data_ptr(), blob_hw[0], blob_hw[1], stream_ptr(dev))
+    check(rc, "dtc_prep_images")
+    del ims
+    return blob, [float(s) for s in scales], [(out_hw[2 * k], out_hw[2 * k + 1]) for k in range(B)]
 
 
 def soft_nms(dets, sigma, overlap_thresh, score_thresh, method):

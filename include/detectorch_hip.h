@@ -23,7 +23,7 @@ extern "C" {
 typedef struct ihipStream_t* dtc_stream_t; /* == hipStream_t */
 
 enum { DTC_OK = 0, DTC_EINVAL = -1, DTC_ELAUNCH = -2, DTC_EWORKSPACE = -3, DTC_EUNSUPPORTED = -4 };
-enum { DTC_F32 = 0, DTC_F16 = 1 };
+enum { DTC_F32 = 0, DTC_F16 = 1, DTC_U8 = 2 /* dtc_prep_images sources only */ };
 
 /* Library / build identification ("gfx950"); lets the host prove the native path is the one that is loaded. */
 const char* dtc_version(void);
@@ -236,6 +236,30 @@ int dtc_bbox_overlaps(const float* boxes, int n, int box_cols, const float* quer
  * call, where every top det is one of all_dets). */
 int dtc_box_voting(const float* top_dets, int n_top, const float* all_dets, int n_all, float thresh,
                    float* top_dets_out, int32_t* n_voters, dtc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * (f)-3  Network-input preparation: prep_im_for_blob + im_list_to_blob  (lib/utils/blob.py:62-87, :27-59)
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* One source image: interleaved HWC, 3 channels in BGR order (as cv2.imread delivers), DTC_U8 or DTC_F32, on the device;
+ * row_stride in elements (>= 3 * width). */
+typedef struct dtc_image {
+  const void* data;
+  int32_t height, width, dtype, row_stride;
+} dtc_image;
+
+/* Host-side plan (no GPU work): per image the scale of blob.py:75-82 (target_size on the short side, capped so that the
+ * long side stays <= max_size), the resized (h, w) cv2.resize(fx=fy=scale) produces, and the blob (H, W) of
+ * im_list_to_blob: max over the batch, rounded up to pad_stride when pad_stride > 1 (fpn_on, :41-44).
+ * im_scales double [batch], out_hw int32 [batch,2], blob_hw int32 [2] -- all host memory. */
+int dtc_prep_plan(const int32_t* heights, const int32_t* widths, int batch, int target_size, int max_size, int pad_stride,
+                  double* im_scales, int32_t* out_hw, int32_t* blob_hw);
+
+/* blob float32 [batch,3,blob_h,blob_w] (device) = for every image: (image - pixel_means) resized bilinearly by
+ * im_scales[b] to out_hw[b], zero padded, channels first.  images / pixel_means (3 doubles, BGR) / im_scales / out_hw are
+ * HOST arrays (the plan above); batch <= 32 per call. */
+int dtc_prep_images(const dtc_image* images, int batch, const double* pixel_means, const double* im_scales,
+                    const int32_t* out_hw, float* blob, int blob_h, int blob_w, dtc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * A6  Soft-NMS  and  A4 (numpy flavour) box decode

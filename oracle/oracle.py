@@ -56,6 +56,10 @@ def lib():
         _LIB.orc_bbox_overlaps.restype = None
         _LIB.orc_box_voting.argtypes = [p, i, p, i, f, p]
         _LIB.orc_box_voting.restype = i
+        _LIB.orc_prep_scale.argtypes = [i, i, i, i]
+        _LIB.orc_prep_scale.restype = C.c_double
+        _LIB.orc_prep_image.argtypes = [p, i, i, i, p, C.c_double, i, i, p, i, i]
+        _LIB.orc_prep_image.restype = None
         _LIB.orc_rle_runs.argtypes = [p, i, i, p]
         _LIB.orc_rle_runs.restype = C.c_longlong
         _LIB.orc_rle_string.argtypes = [p, C.c_longlong, p]
@@ -249,3 +253,24 @@ def box_voting(top_dets, all_dets, thresh):
     out = np.zeros_like(t)
     lib().orc_box_voting(t.ctypes.data, t.shape[0], a.ctypes.data, a.shape[0], float(np.float32(thresh)), out.ctypes.data)
     return out
+
+
+def prep_images(images, pixel_means=(122.7717, 115.9465, 102.9801), target_size=800, max_size=1333, pad_stride=32):
+    """blob.py:62-87 + :27-59 for a list of HWC BGR images (uint8 or float32) -> (blob float32 [B,3,Hb,Wb], scales list)."""
+    means = np.asarray(pixel_means, np.float64)
+    scales, sizes = [], []
+    for im in images:
+        h, w = im.shape[:2]
+        s = lib().orc_prep_scale(h, w, int(target_size), int(max_size))
+        scales.append(s)
+        sizes.append((max(int(np.round(h * s)), 1), max(int(np.round(w * s)), 1)))      # np.round == rint: half to even
+    Hb, Wb = max(a for a, _ in sizes), max(b for _, b in sizes)
+    if pad_stride > 1:
+        Hb = int(np.ceil(Hb / float(pad_stride)) * pad_stride); Wb = int(np.ceil(Wb / float(pad_stride)) * pad_stride)
+    blob = np.zeros((len(images), 3, Hb, Wb), np.float32)
+    for b, im in enumerate(images):
+        u8 = im.dtype == np.uint8
+        src = np.ascontiguousarray(im if u8 else im.astype(np.float32))
+        lib().orc_prep_image(src.ctypes.data, 1 if u8 else 0, src.shape[0], src.shape[1], means.ctypes.data, scales[b],
+                             sizes[b][0], sizes[b][1], blob[b].ctypes.data, Hb, Wb)
+    return blob, scales
