@@ -44,21 +44,54 @@ def parse():
     return ap.parse_args()
 
 
-def _cpu_warm(_):
-    """Make every pool worker import the oracle chain (and load liboracle.so) before the timed region."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import chain  # noqa: E402,F401
-    time.sleep(0.3)
-    return os.getpid()
-
-
-def _cpu_one_image(job):
-    """Worker of the all-cores leg: one image through the oracle chain (one process per image, no shared state)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import chain  # noqa: E402
-    t0 = time.perf_counter()
-    chain.fpn_hot_path(*job)
-    return time.perf_counter() - t0
+def _cpu_all_cores(jobs, budget_s=60.0):
+    """All-cores figure: P = min(host cores, 32) worker processes (oracle/cpu_worker.py, one image each, the
+    n distinct images reused round-robin), inputs handed over as memory-mapped .npy files, a file barrier, wall clock from
+    the common start to the last finish.  Returns images/sec over all workers."""
+    import shutil
+    import subprocess
+    import tempfile
+    n = len(jobs)
+    procs = max(1, min(os.cpu_count() or 1, 32))
+    need = sum(sum(a.nbytes for a in (j[0] + j[1] + j[2])) + j[3].nbytes + j[4].nbytes + j[5].nbytes for j in jobs) + (1 << 20)
+    base = None       # default temp dir unless /dev/shm has room for the inputs (containers often cap it at 64 MB)
+    if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2 * need:
+        base = "/dev/shm"
+    d = tempfile.mkdtemp(prefix="dtc_cpu_", dir=base)
+    ws = []
+    try:
+        for k, (rc, rb, ft, score, pred, masks, sf, imsz, ph, pw) in enumerate(jobs):
+            for l in range(5):
+                np.save(os.path.join(d, "img%d_cls%d.npy" % (k, l)), rc[l]); np.save(os.path.join(d, "img%d_bbox%d.npy" % (k, l)), rb[l])
+            for l in range(4):
+                np.save(os.path.join(d, "img%d_feat%d.npy" % (k, l)), ft[l])
+            for name, arr in (("score", score), ("pred", pred), ("masks", masks), ("imsize", imsz)):
+                np.save(os.path.join(d, "img%d_%s.npy" % (k, name)), arr)
+            np.save(os.path.join(d, "img%d_meta.npy" % k), np.array([sf, ph, pw], np.float64))
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        for w in range(procs):
+            ws.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), d, str(w % n), str(w)],
+                                       env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+        t_end = time.time() + budget_s
+        while sum(os.path.exists(os.path.join(d, "ready%d" % w)) for w in range(procs)) < procs:
+            if time.time() > t_end or any(p.poll() not in (None, 0) for p in ws):
+                raise RuntimeError("workers did not become ready")
+            time.sleep(0.01)
+        open(os.path.join(d, "go"), "w").close()
+        while sum(os.path.exists(os.path.join(d, "done%d" % w)) for w in range(procs)) < procs:
+            if time.time() > t_end:
+                raise RuntimeError("workers did not finish")
+            time.sleep(0.005)
+        spans = [tuple(float(v) for v in open(os.path.join(d, "done%d" % w)).read().split()) for w in range(procs)]
+        wall = max(e for _, e in spans) - min(s for s, _ in spans)
+        return {"value": round(procs / wall, 4), "unit": "images/sec", "processes": procs,
+                "note": "%d worker processes x 1 image each (the %d sample images round-robin), common start, wall clock to the "
+                        "last finish; single-threaded oracle per process" % (procs, n)}
+    finally:
+        for p in ws:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def cpu_baseline(inputs, path, n_images):
@@ -85,17 +118,9 @@ def cpu_baseline(inputs, path, n_images):
            "sample": "%d images of the same synthetic cfg3 workload (R=1000, C=256), oracle/oracle.c via ctypes, "
                      "%.1f s CPU; per-stage s/img: %s" % (n, dt, {k: round(v / n, 4) for k, v in T.items()}),
            "host_cpus": os.cpu_count()}
-    try:   # all-cores figure: image-parallel, one worker process per image (spawn: no CUDA state is inherited)
-        import multiprocessing as mp
-        procs = max(1, min(n, os.cpu_count() or 1))
-        with mp.get_context("spawn").Pool(procs) as pool:
-            pool.map(_cpu_warm, range(4 * procs), chunksize=1)    # every worker warm (imports, liboracle.so)
-            t0 = time.perf_counter()
-            pool.map(_cpu_one_image, jobs, chunksize=1)
-            wall = time.perf_counter() - t0
-        out["all_cores"] = {"value": round(n / wall, 4), "unit": "images/sec", "processes": procs,
-                            "note": "same %d images, one process per image, wall clock incl. argument pickling" % n}
-    except Exception as e:   # the single-core figure above is the contract; this one is informational
+    try:   # informational; the single-core figure above is the contract
+        out["all_cores"] = _cpu_all_cores(jobs)
+    except Exception as e:
         out["all_cores"] = {"error": repr(e)}
     return out
 
