@@ -6,6 +6,8 @@
 // idx_restore) it emits what the multi-level RoIAlign kernel consumes directly: rois5 in collected order + a level id per
 // RoI, so the pooled features come out already "restored" (no cat / index_select, lib/model/detector.py:266-270).
 #include "block_sort.h"
+#include <stdlib.h>
+
 #include "dtc_common.h"
 
 namespace dtc {
@@ -27,6 +29,7 @@ struct FpnParams {
   const float* in_scores;    // [B, L_in, P]     (NULL: no sort, take the first counts[b*L_in] rows of level 0 as they are)
   const int32_t* in_counts;  // [B, L_in]
   int L_in, P, top_n, k_min, k_max;
+  int band_log2;             // visiting-order band height in feature rows (log2)
   int inputs_sorted;         // every input list is already in (score desc) order (NMS output): merge by rank, no sort
   float* rois5;              // [B, top_n, 5]   (b, x1, y1, x2, y2) in collected (score) order
   float* roi_scores;         // [B, top_n]      (may be NULL)
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(Fpn
     reinterpret_cast<float4*>(p.rois_by_level)[(size_t)b * p.top_n + dst] = make_float4(o[1], o[2], o[3], o[4]);
   }
   if (p.roi_order) {
-    // visiting order for RoIAlign: (level, y centre, rank).  Purely a performance hint; any permutation is correct.
+    // visiting order for RoIAlign.  Purely a performance hint; any permutation is correct.
     __syncthreads();
     const int np2o = next_pow2(p.top_n);
     for (int r = tid; r < np2o; r += kFpnThreads) {
@@ -174,8 +177,15 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(Fpn
       if (r < p.top_n) {
         const int lvl = p.roi_levels[(size_t)b * p.top_n + r];
         const float* o = p.rois5 + ((size_t)b * p.top_n + r) * 5;
+        // (level, band of 32 feature rows, x centre, rank): RoIs that are neighbours in the order overlap in BOTH directions,
+        // so a 128-byte feature line (32 pixels of one channel row) is re-used by the next few RoIs while it is still in
+        // the XCD's L2 -- with a y-only order the concurrently pooled RoIs span the whole map width and a line is evicted
+        // before its next user arrives (EA reads per box-head launch: 1.79 GB -> see profiles/).
         const uint32_t yc = (uint32_t)fminf(fmaxf((o[2] + o[4]) * 0.5f, 0.f), 65535.f);
-        k = ((uint64_t)(lvl < 0 ? 15u : (uint32_t)lvl) << 48) | ((uint64_t)yc << 32) | (uint32_t)r;
+        const uint32_t xc = (uint32_t)fminf(fmaxf((o[1] + o[3]) * 0.5f, 0.f), 65535.f);
+        const uint32_t lv4 = lvl < 0 ? 15u : (uint32_t)lvl;
+        const uint32_t band = yc >> min((uint32_t)p.band_log2 + (uint32_t)p.k_min + lv4, 15u);    // 2^band_log2 feature rows of this level, in image pixels
+        k = ((uint64_t)lv4 << 52) | ((uint64_t)(band & 0xfffu) << 40) | ((uint64_t)xc << 20) | (uint32_t)r;
       }
       keys[r] = k;
     }
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(Fpn
       block_bitonic_sort<kFpnThreads>(keys, np2o);
     }
     for (int i = tid; i < p.top_n; i += kFpnThreads) {
-      const int r = (int)(uint32_t)keys[i];
+      const int r = (int)(keys[i] & 0xfffffu);
       p.roi_order[(size_t)b * p.top_n + i] = b * p.top_n + r;
       if (p.roi_desc) {
         const float* o = p.rois5 + ((size_t)b * p.top_n + r) * 5;
@@ -227,6 +237,7 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
   p.in_boxes = in_boxes; p.in_scores = in_scores; p.in_counts = in_counts; p.L_in = n_in_levels; p.P = in_stride;
   p.top_n = post_nms_top_n; p.k_min = k_min; p.k_max = k_max; p.inputs_sorted = inputs_sorted; p.rois5 = rois5; p.roi_scores = roi_scores;
   p.roi_levels = roi_levels; p.n_out = n_out; p.rois_by_level = rois_by_level; p.level_counts = level_counts;
+  p.band_log2 = getenv("DTC_FPN_BAND_LOG2") ? atoi(getenv("DTC_FPN_BAND_LOG2")) : 5;
   p.idx_restore = idx_restore; p.roi_order = roi_order; p.roi_desc = roi_order ? roi_desc : nullptr;
   size_t smem = in_scores ? (size_t)dtc::next_pow2((int)n_max) * sizeof(uint64_t) : 16;
   if (in_scores && inputs_sorted) smem = (size_t)post_nms_top_n * sizeof(uint64_t) + (size_t)n_max * sizeof(float) + 16;
