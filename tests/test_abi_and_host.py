@@ -131,3 +131,16 @@ def test_argument_validation_returns_error_codes_without_touching_the_gpu():
     lvl = (hip.RpnLevel * 1)()
     assert L.dtc_rpn_topk_decode_workspace_bytes(lvl, 1, 1, 0) == 0                                        # invalid level -> 0
     assert L.dtc_rpn_topk_decode(None, 1, 1, 800., 1333., 0., None, 0, None, None, None, 0, None) == EINVAL
+
+
+def test_header_is_plain_c_and_cxx():
+    """The boundary is a C ABI: include/detectorch_hip.h must compile as C99 (pedantic) and as C++11, with no torch/HIP types."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "detectorch_hip.h")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.check_call(["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", hdr])
+    subprocess.check_call(["g++", "-x", "c++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", hdr])
+    code = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)          # declarations only (comments cite torch call sites)
+    assert "torch" not in code.lower().replace("detectorch", "") and "#include <hip" not in code and "at::" not in code
