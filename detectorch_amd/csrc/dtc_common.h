@@ -36,6 +36,23 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half_rn(v); }
 
+// bfloat16 storage type (DTC_BF16): the upper 16 bits of a float32; conversion to float32 is exact, from float32 rounds to
+// nearest even (NaN stays NaN).  No arithmetic happens in bf16: the kernels accumulate in float32.
+struct bf16_t { uint16_t bits; };
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return __uint_as_float((uint32_t)v.bits << 16); }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) {
+  uint32_t u = __float_as_uint(v);
+  bf16_t r;
+  if ((u & 0x7fffffffu) > 0x7f800000u) { r.bits = (uint16_t)((u >> 16) | 0x0040u); return r; }   // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  r.bits = (uint16_t)(u >> 16);
+  return r;
+}
+__device__ __forceinline__ float4 bf16x4_to_f32(uint2 r) {
+  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                     __uint_as_float(r.y & 0xffff0000u));
+}
+
 __host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace dtc

@@ -288,6 +288,7 @@ struct StagerNHWC {
     const __half2 a = *reinterpret_cast<const __half2*>(&r.x), b = *reinterpret_cast<const __half2*>(&r.y);
     return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
   }
+  static __device__ __forceinline__ float4 load4(const bf16_t* p) { return bf16x4_to_f32(*reinterpret_cast<const uint2*>(p)); }
   __device__ __forceinline__ void init(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int npix, int cts) {
     const int quads = cts >> 2;
     cq = threadIdx.x % quads;
@@ -353,6 +354,7 @@ struct StagerRow4 {
     const __half2 a = *reinterpret_cast<const __half2*>(&r.x), b = *reinterpret_cast<const __half2*>(&r.y);
     return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
   }
+  static __device__ __forceinline__ float4 load4(const bf16_t* p) { return bf16x4_to_f32(*reinterpret_cast<const uint2*>(p)); }
   __device__ __forceinline__ void init(const dtc_feat_level& L, int y0, int xa, int ng, int wh, int cts) {
     const int tid = threadIdx.x;
     ch = tid & (cts - 1);
@@ -625,6 +627,10 @@ template <> struct Vec4Load<__half> {
     const __half2 a = *reinterpret_cast<const __half2*>(&r.x), b = *reinterpret_cast<const __half2*>(&r.y);
     return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
   }
+};
+
+template <> struct Vec4Load<bf16_t> {
+  static __device__ __forceinline__ float4 ld(const bf16_t* p) { return bf16x4_to_f32(*reinterpret_cast<const uint2*>(p)); }
 };
 
 template <typename TIn, typename TOut>
@@ -1321,6 +1327,9 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
     if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return dtc::launch_nhwc<__half, float>(p, s);
     if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return dtc::launch_nhwc<__half, __half>(p, s);
     if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return dtc::launch_nhwc<float, __half>(p, s);
+    if (in_dtype == DTC_BF16 && out_dtype == DTC_F32) return dtc::launch_nhwc<dtc::bf16_t, float>(p, s);
+    if (in_dtype == DTC_BF16 && out_dtype == DTC_BF16) return dtc::launch_nhwc<dtc::bf16_t, dtc::bf16_t>(p, s);
+    if (in_dtype == DTC_F32 && out_dtype == DTC_BF16) return dtc::launch_nhwc<float, dtc::bf16_t>(p, s);
     return DTC_EUNSUPPORTED;
   }
   // LDS-DMA variant: bit-exact and tested, but SLOWER on MI355X than the register-prefetch kernel (8000 RoIs: 0.84 vs
@@ -1347,12 +1356,18 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
     if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return dtc::launch_lds<__half, float>(p, s);
     if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return dtc::launch_lds<__half, __half>(p, s);
     if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return dtc::launch_lds<float, __half>(p, s);
+    if (in_dtype == DTC_BF16 && out_dtype == DTC_F32) return dtc::launch_lds<dtc::bf16_t, float>(p, s);
+    if (in_dtype == DTC_BF16 && out_dtype == DTC_BF16) return dtc::launch_lds<dtc::bf16_t, dtc::bf16_t>(p, s);
+    if (in_dtype == DTC_F32 && out_dtype == DTC_BF16) return dtc::launch_lds<float, dtc::bf16_t>(p, s);
     return DTC_EUNSUPPORTED;
   }
   if (in_dtype == DTC_F32 && out_dtype == DTC_F32) return dtc::launch_general<float, float>(p, s);
   if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return dtc::launch_general<__half, float>(p, s);
   if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return dtc::launch_general<__half, __half>(p, s);
   if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return dtc::launch_general<float, __half>(p, s);
+  if (in_dtype == DTC_BF16 && out_dtype == DTC_F32) return dtc::launch_general<dtc::bf16_t, float>(p, s);
+  if (in_dtype == DTC_BF16 && out_dtype == DTC_BF16) return dtc::launch_general<dtc::bf16_t, dtc::bf16_t>(p, s);
+  if (in_dtype == DTC_F32 && out_dtype == DTC_BF16) return dtc::launch_general<float, dtc::bf16_t>(p, s);
   return DTC_EUNSUPPORTED;
 }
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DETECTORCH_HIP_LIB") or os.path.join(_HERE, "lib", "libdetectorch_hip.so")
 
 DTC_OK = 0
-DTC_F32, DTC_F16 = 0, 1
+DTC_F32, DTC_F16, DTC_U8, DTC_BF16 = 0, 1, 2, 3
 DTC_MAX_LEVELS = 8
 _ERR = {-1: "DTC_EINVAL", -2: "DTC_ELAUNCH", -3: "DTC_EWORKSPACE", -4: "DTC_EUNSUPPORTED"}
 
@@ -119,7 +119,9 @@ def _dtype_code(t):
         return DTC_F32
     if t == torch.float16:
         return DTC_F16
-    raise TypeError("detectorch_hip supports float32 / float16 features, got %s" % t)
+    if t == torch.bfloat16:
+        return DTC_BF16
+    raise TypeError("detectorch_hip supports float32 / float16 / bfloat16 features, got %s" % t)
 
 
 def _require_cuda(*tensors):

@@ -23,7 +23,7 @@ extern "C" {
 typedef struct ihipStream_t* dtc_stream_t; /* == hipStream_t */
 
 enum { DTC_OK = 0, DTC_EINVAL = -1, DTC_ELAUNCH = -2, DTC_EWORKSPACE = -3, DTC_EUNSUPPORTED = -4 };
-enum { DTC_F32 = 0, DTC_F16 = 1, DTC_U8 = 2 /* dtc_prep_images sources only */ };
+enum { DTC_F32 = 0, DTC_F16 = 1, DTC_U8 = 2 /* dtc_prep_images sources only */, DTC_BF16 = 3 /* RoIAlign features / output */ };
 
 /* Library / build identification ("gfx950"); lets the host prove the native path is the one that is loaded. */
 const char* dtc_version(void);
@@ -57,7 +57,7 @@ typedef struct dtc_feat_level {
 /* Multi-level RoIAlign in ONE launch: replaces the per-level Python loop + torch.cat + index_select of
  * lib/model/detector.py:263-270 and lib/model/detector.py:101-106.  rois float32 [R,roi_cols] (roi_cols 5, or 4 =
  * batch 0 like lib/cppcuda/roi_align_cpu.cpp:143-147); roi_levels int32 [R] = index into levels[] (NULL: level 0);
- * out [R,C,PH,PW] contiguous, written in roi order.  in_dtype/out_dtype: DTC_F32 or DTC_F16 (fp32 accumulate). */
+ * out [R,C,PH,PW] contiguous, written in roi order.  in_dtype/out_dtype: DTC_F32, DTC_F16 or DTC_BF16 (always fp32 accumulate; f16 and bf16 do not mix). */
 int dtc_roi_align_forward(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype, const float* rois,
                           int roi_cols, const int32_t* roi_levels, int n_rois, int pooled_h, int pooled_w,
                           int sampling_ratio, void* out, int out_dtype, dtc_stream_t stream);

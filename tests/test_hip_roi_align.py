@@ -189,3 +189,27 @@ def test_experimental_kernel_variants_bit_exact(hip, oracle, env, monkeypatch):
         out = hip.roi_align_forward([cu(f) for f in feats], synth.FPN_ROI_SCALES, cu(rois5), ph, ph, sr,
                                     roi_levels=cu(lv)).cpu().numpy()
         assert np.array_equal(out, ref), (env, C, ph, sr)
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_bfloat16_features_and_output(hip, oracle, layout):
+    """bf16 feature maps (what an MI355X bf16 backbone emits) / bf16 pooled output for the fc6 GEMM: fp32 accumulation, so
+    bf16-in -> fp32-out equals the oracle on the up-cast maps bit for bit; bf16-out is that result rounded to nearest even."""
+    feats, rois5, lv, _ = _fpn_case(oracle, 150, 72, 7, 2, 31, batch=2)
+    tb = [cu(f).to(torch.bfloat16) for f in feats]
+    up = [t.float().cpu().numpy() for t in tb]
+    ref = np.zeros((150, 72, 7, 7), np.float32)
+    for l in range(4):
+        m = lv == l
+        if m.any():
+            ref[m] = oracle.roi_align_forward(up[l], rois5[m], 7, 7, synth.FPN_ROI_SCALES[l], 2)
+    if layout == "nhwc":
+        tb = [t.contiguous(memory_format=torch.channels_last) for t in tb]
+    out32 = hip.roi_align_forward(tb, synth.FPN_ROI_SCALES, cu(rois5), 7, 7, 2, roi_levels=cu(lv))
+    assert out32.dtype == torch.float32 and np.array_equal(out32.cpu().numpy(), ref)
+    out16 = hip.roi_align_forward(tb, synth.FPN_ROI_SCALES, cu(rois5), 7, 7, 2, roi_levels=cu(lv), out_dtype=torch.bfloat16)
+    assert out16.dtype == torch.bfloat16
+    assert torch.equal(out16.cpu(), torch.from_numpy(ref).to(torch.bfloat16))          # same round-to-nearest-even
+    f32in = hip.roi_align_forward([cu(u) for u in up], synth.FPN_ROI_SCALES, cu(rois5), 7, 7, 2, roi_levels=cu(lv),
+                                  out_dtype=torch.bfloat16)
+    assert torch.equal(f32in.cpu(), out16.cpu())
