@@ -29,6 +29,8 @@ struct RoiAlignParams {
   void* out;
   int n_levels, channels, roi_cols, n_rois, pooled_h, pooled_w, sampling_ratio, ch_tile;
   int ch_block;   // channels per workgroup of the LDS kernel (multiple of 64): setup (tables, window) is paid once per block
+  int quad_align; // 1: widen staged windows to 4-pixel boundaries (aligned lane quads; see roi_align_fwd_lds)
+  int row_slots;  // 1: row-slot chunk enumeration (a row piece belongs to one wave-instruction)
   int cts64;      // 1: allow 64-channel sub-tiles (one bin per ds_read_b128 lane group: conflict-free taps)
   int row4;       // 1: 16-byte row pieces for NCHW levels whose rows are 4-element aligned (StagerRow4)
   int xcd_remap;  // 1: workgroup -> work-item mapping keeps each XCD on a contiguous range of the visiting order
@@ -232,6 +234,34 @@ struct StagerNCHW {
       lbase[k] = lp * ctp + cl;
       pix += 64; px += r64; py += q64;
       if (px >= ww) { px -= ww; py++; }
+    }
+  }
+  // Row-slot enumeration: chunk k of wave wv is the 16-pixel segment (row, seg) = divmod(wv + 4k, nseg) of the window, so a
+  // row piece is consumed by ONE wave-instruction (x 4 channel planes).  With the linear pixel order of init() a row piece is
+  // split between two chunks that belong to different waves; the 32 KB L1 (256 lines, ~1200 lines in flight per CU) has
+  // evicted the line by the time the second wave asks for it: measured 6.5 K line fills per RoI against 3.1 K distinct lines.
+  __device__ __forceinline__ void init_rows(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int npix, int cts) {
+    const int tid = threadIdx.x;
+    const int pl = tid & 15, wv = tid >> 6;
+    cl = (tid >> 4) & 3;
+    stride_c = L.stride_c;
+    const int ctp = cts + kLdsPad;
+    const int nseg = (ww + 15) >> 4;
+    const int nslots = wh * nseg;
+    nk = ceil_div(nslots, kRoiAlignThreads / 64);
+    const float rinv = 1.0f / (float)nseg;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int sl = wv + (kRoiAlignThreads / 64) * k;
+      const int slc = min(sl, nslots - 1);
+      const int row = (int)(((float)slc + 0.5f) * rinv);          // exact for small integers
+      const int seg = slc - row * nseg;
+      const int px = seg * 16 + pl;
+      const bool ok = sl < nslots && px < ww;
+      const int lx = min(px, ww - 1);                             // lanes past the row end re-read its last pixel (same line)
+      voff[k] = (uint32_t)(((int64_t)(y0 + row) * L.stride_h + (int64_t)(x0 + lx) * L.stride_w + (int64_t)cl * L.stride_c) *
+                           (int64_t)sizeof(TIn));
+      lbase[k] = (ok ? row * ww + px : npix) * ctp + cl;          // ... and write to the dummy slot
     }
   }
   // full sub-tile (all cts channels valid)
@@ -549,7 +579,28 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
           (long long)(npa + 1) * (c + kLdsPad) + (long long)c * bins <= avail) cts = c;
     if (cts != 0) { x0 = xa; ww = 4 * ng; npix = npa; } else row4 = false;
   }
-  // ... otherwise one dword per lane; the per-thread share of the window must fit the 32 prefetch registers (npix * cts <= 8192)
+  // Quad alignment (measured with tools/micro/tcp_access_patterns.hip): the texture addresser coalesces a wave's dword
+  // loads per QUAD of lanes -- four lanes reading four consecutive dwords of one 16-byte-aligned unit are one L1 access and
+  // neighbouring quads merge into 64-byte accesses (6-10 accesses per wave-instruction); a quad that straddles a row break
+  // or starts off a 16-byte boundary degrades the whole instruction to one access per lane (~40).  With an arbitrary
+  // window (x0, ww ~ 9) nearly every quad straddles.  So the staged window is widened to 4-pixel boundaries whenever the
+  // level's rows are 4-element aligned: chunks of 16 lanes then always hold whole aligned quads of one row.  The extra
+  // columns are real neighbouring pixels (never sampled); the axis tables are relative to the widened origin.
+  if (!row4 && p.quad_align && L.stride_w == 1 && ((L.width | L.stride_h | L.stride_c | L.stride_n) & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(L.data) & (4 * sizeof(TIn) - 1)) == 0) {
+    x0 = x0 & ~3;
+    ww = ((x1 >> 2) - (x0 >> 2) + 1) * 4;
+    npix = wh * ww;
+  }
+  bool row_slots = false;
+  if (!row4 && p.row_slots && L.stride_c != 1) {
+    const int nslots = wh * ((ww + 15) >> 4);
+#pragma unroll
+    for (int c = 32; c >= 8; c >>= 1)      // K = 128 / c chunks per thread, 4 slots per chunk round
+      if (cts == 0 && nslots * c <= 512 && (long long)(npix + 1) * (c + kLdsPad) + (long long)c * bins <= avail) cts = c;
+    row_slots = cts != 0;
+  }
+  // one dword per lane; the per-thread share of the window must fit the 32 prefetch registers (npix * cts <= 8192)
   if (p.cts64 && cts == 0 && L.stride_c != 1 && nc >= 64 && npix <= 128 &&
       (long long)(npix + 1) * (64 + kLdsPad) + 64LL * bins <= avail) cts = 64;
 #pragma unroll
@@ -598,8 +649,13 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
     StagerNHWC<TIn> st; st.init(L, y0, x0, ww, wh, npix, cts);
     run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out);
   } else {
-    const int nk = ceil_div(ceil_div(npix, 16), kRoiAlignThreads / 64);
-    if (cts == 64) { StagerNCHW<TIn, 2, 16> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
+    const int nk = row_slots ? ceil_div(wh * ((ww + 15) >> 4), kRoiAlignThreads / 64)
+                             : ceil_div(ceil_div(npix, 16), kRoiAlignThreads / 64);
+    if (row_slots) {
+      if (nk <= 4) { StagerNCHW<TIn, 4, 8> st; st.init_rows(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
+      else if (nk <= 8) { StagerNCHW<TIn, 8, 4> st; st.init_rows(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
+      else { StagerNCHW<TIn, 16, 2> st; st.init_rows(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
+    } else if (cts == 64) { StagerNCHW<TIn, 2, 16> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
     else if (nk <= 4) { StagerNCHW<TIn, 4, 8> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
     else if (nk <= 8) { StagerNCHW<TIn, 8, 4> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
     else { StagerNCHW<TIn, 16, 2> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
@@ -1309,6 +1365,10 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   p.xcd_remap = getenv("DTC_RA_NO_XCD") == nullptr;
   p.row4 = getenv("DTC_RA_ROW4") != nullptr;      // measured neutral (0.73 vs 0.71 ms): off by default, A/B knob
   p.cts64 = getenv("DTC_RA_CTS64") != nullptr;
+  // both measured (tools/tcp_probe_quad.sh): L1 accesses halve (187 M -> 91 M / 84 M per launch) but the line fills do not
+  // change (51.8 M) and the launch gets slower (0.755 -> 0.788 / 0.869 ms): off by default, kept as tested A/B knobs
+  p.quad_align = getenv("DTC_RA_QUAD") != nullptr;
+  p.row_slots = getenv("DTC_RA_ROWSLOTS") != nullptr;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // fixed sampling grid with small tables -> LDS-staged kernel; adaptive sampling (sampling_ratio <= 0) -> general kernel
   // LDS-staged kernel for every pooled size whose output slab fits; adaptive sampling (sampling_ratio <= 0) included
