@@ -563,7 +563,9 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   const int wh = y1 - y0 + 1;
   int npix = wh * ww;
   // sub-tile width: largest CTs whose window (+1 dummy pixel) + output slab fit
-  const int avail = lds_floats - kLdsTableFloats;
+  // the tables take what this RoI needs (28 entries for 7x7 bins x 2 samples), not the 4 KB worst case: ~3.5 KB more window
+  const int tabf = ((ny + nx) * 4 + 15) & ~15;
+  const int avail = lds_floats - tabf;
   int cts = 0;
   // 16-byte row pieces (StagerRow4) when every row of this level starts on a 4-element boundary
   bool row4 = p.row4 && L.stride_w == 1 && ((L.width | L.stride_h | L.stride_c | L.stride_n) & 3) == 0 &&
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   else if (tid < ny + nx) { AxisEntry e = ytab[tid]; LdsAxis o; o.lo = (e.lo - x0) * (cts + kLdsPad); o.hi = (e.hi - x0) * (cts + kLdsPad); o.l = e.l; o.h = e.h; yl[tid] = o; }
   LdsGeom G;
   G.ytab = yl; G.xtab = xl;
-  G.slab = lds + kLdsTableFloats;                 // [cts][bins] output staging
+  G.slab = lds + tabf;                            // [cts][bins] output staging (16-float aligned)
   G.win = G.slab + cts * bins;                    // [npix + 1][cts + 4]  (cts*bins is a multiple of 4 -> 16 B aligned)
   G.cts = cts; G.bins = bins; G.gh = gh; G.gw = gw; G.pooled_w = p.pooled_w; G.nc = nc; G.count = count;
   G.inv_count = hd.inv_count;
@@ -1364,7 +1366,7 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   if (getenv("DTC_RA_CHBLOCK")) p.ch_block = atoi(getenv("DTC_RA_CHBLOCK"));
   p.xcd_remap = getenv("DTC_RA_NO_XCD") == nullptr;
   p.row4 = getenv("DTC_RA_ROW4") != nullptr;      // measured neutral (0.73 vs 0.71 ms): off by default, A/B knob
-  p.cts64 = getenv("DTC_RA_CTS64") != nullptr;
+  p.cts64 = getenv("DTC_RA_NO_CTS64") == nullptr;   // 64-channel sub-tiles for windows <= 128 px: +4 % on the bench workload
   // both measured (tools/tcp_probe_quad.sh): L1 accesses halve (187 M -> 91 M / 84 M per launch) but the line fills do not
   // change (51.8 M) and the launch gets slower (0.755 -> 0.788 / 0.869 ms): off by default, kept as tested A/B knobs
   p.quad_align = getenv("DTC_RA_QUAD") != nullptr;
