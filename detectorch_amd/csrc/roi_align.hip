@@ -15,6 +15,8 @@
 //   * element strides instead of a fixed NCHW layout, fp16 or fp32 features, fp32 accumulation.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "dtc_common.h"
 
 namespace dtc {
@@ -31,6 +33,7 @@ struct RoiAlignParams {
   int ch_block;   // channels per workgroup of the LDS kernel (multiple of 64): setup (tables, window) is paid once per block
   int quad_align; // 1: widen staged windows to 4-pixel boundaries (aligned lane quads; see roi_align_fwd_lds)
   int row_slots;  // 1: row-slot chunk enumeration (a row piece belongs to one wave-instruction)
+  int pair_loads; // 1: 2-byte features are gathered as pixel pairs (StagerNCHW2)
   int cts64;      // 1: allow 64-channel sub-tiles (one bin per ds_read_b128 lane group: conflict-free taps)
   int row4;       // 1: 16-byte row pieces for NCHW levels whose rows are 4-element aligned (StagerRow4)
   int xcd_remap;  // 1: workgroup -> work-item mapping keeps each XCD on a contiguous range of the visiting order
@@ -297,6 +300,80 @@ struct StagerNCHW {
 #pragma unroll
         for (int k = 0; k < K; k++)
           if (k < nk) win[lbase[k] + 4 * g] = v[g][k];
+      }
+    }
+  }
+};
+
+// NCHW, pixel-PAIR loads: lane -> (pair of neighbouring pixels in a 16-pair chunk, channel in a group of 4).  The window is
+// widened to even columns (rows of these levels start on even elements) and a lane loads both pixels with ONE instruction
+// -- a dword for fp16 / bf16, a dwordx2 for fp32 -- so a 16-lane group reads one contiguous row piece with half the lanes.
+// Measured on MI355X: fp16 NCHW 4888 -> 8336 images/s (one 2-byte load per lane makes the texture addresser issue an
+// access per lane).  The pair stays packed in registers until commit, where it becomes two float32 LDS pixels.  Lanes past
+// the window duplicate the last pair (same value to the same LDS words: benign).
+template <typename TIn> struct PairOf { using type = uint32_t; };
+template <> struct PairOf<float> { using type = float2; };
+template <typename TIn> __device__ __forceinline__ float pair_lo(uint32_t u);
+template <typename TIn> __device__ __forceinline__ float pair_hi(uint32_t u);
+template <> __device__ __forceinline__ float pair_lo<__half>(uint32_t u) { return __half2float(__ushort_as_half((unsigned short)(u & 0xffffu))); }
+template <> __device__ __forceinline__ float pair_hi<__half>(uint32_t u) { return __half2float(__ushort_as_half((unsigned short)(u >> 16))); }
+template <> __device__ __forceinline__ float pair_lo<bf16_t>(uint32_t u) { return __uint_as_float(u << 16); }
+template <> __device__ __forceinline__ float pair_hi<bf16_t>(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+template <typename TIn> __device__ __forceinline__ float pair_lo(float2 u) { return u.x; }
+template <typename TIn> __device__ __forceinline__ float pair_hi(float2 u) { return u.y; }
+
+template <typename TIn, int K, int G>
+struct StagerNCHW2 {
+  using P = typename PairOf<TIn>::type;
+  P v[G][K];
+  uint32_t voff[K];
+  int32_t lbase[K];
+  int cl, nk, ctp;
+  int64_t stride_c;
+  // (x0, ww) already widened to even columns; wwp = ww / 2 pairs per row
+  __device__ __forceinline__ void init(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int cts) {
+    const int tid = threadIdx.x;
+    const int pl = tid & 15, wv = tid >> 6;
+    cl = (tid >> 4) & 3;
+    stride_c = L.stride_c;
+    ctp = cts + kLdsPad;
+    const int wwp = ww >> 1, npair = wh * wwp;
+    nk = ceil_div(ceil_div(npair, 16), kRoiAlignThreads / 64);
+    const float rinv = 1.0f / (float)wwp;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int pr = min(wv * 16 + pl + 64 * k, npair - 1);
+      const int py = (int)(((float)pr + 0.5f) * rinv);            // exact for pr < 2^12
+      const int pp = pr - py * wwp;
+      voff[k] = (uint32_t)(((int64_t)(y0 + py) * L.stride_h + (int64_t)(x0 + 2 * pp) + (int64_t)cl * L.stride_c) *
+                           (int64_t)sizeof(TIn));
+      lbase[k] = (py * ww + 2 * pp) * ctp + cl;
+    }
+  }
+  __device__ __forceinline__ void issue(const TIn* cbase, int cts, int nvalid) {
+    const char* cb = reinterpret_cast<const char*>(cbase);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      if (4 * g < cts) {
+        const int c = min(4 * g + cl, nvalid - 1) - cl;            // channel tail: clamp the plane, never stored
+        const char* gb = cb + (int64_t)c * stride_c * (int64_t)sizeof(TIn);
+#pragma unroll
+        for (int k = 0; k < K; k++)
+          if (k < nk) v[g][k] = *reinterpret_cast<const P*>(gb + voff[k]);
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(float* win, int cts) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      if (4 * g < cts) {
+#pragma unroll
+        for (int k = 0; k < K; k++)
+          if (k < nk) {
+            float* d = win + lbase[k] + 4 * g;
+            d[0] = pair_lo<TIn>(v[g][k]);
+            d[ctp] = pair_hi<TIn>(v[g][k]);
+          }
       }
     }
   }
@@ -594,8 +671,18 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
     ww = ((x1 >> 2) - (x0 >> 2) + 1) * 4;
     npix = wh * ww;
   }
+  // pixel-pair loads (StagerNCHW2) when rows start on even elements: dword pairs for fp16/bf16, dwordx2 pairs for fp32
+  const bool pairs = p.pair_loads && (sizeof(TIn) == 2 || p.pair_loads > 1) && !row4 && L.stride_c != 1 && L.stride_w == 1 &&
+                     ((L.width | L.stride_h | L.stride_c | L.stride_n) & 1) == 0 &&
+                     (reinterpret_cast<uintptr_t>(L.data) & (2 * sizeof(TIn) - 1)) == 0;
+  const int pair_budget = sizeof(TIn) == 2 ? 8192 : 4096;   // pairs x channels a workgroup holds in 32 registers per thread
+  if (pairs) {
+    x0 = x0 & ~1;
+    ww = ((x1 >> 1) - (x0 >> 1) + 1) * 2;
+    npix = wh * ww;
+  }
   bool row_slots = false;
-  if (!row4 && p.row_slots && L.stride_c != 1) {
+  if (!row4 && !pairs && p.row_slots && L.stride_c != 1) {
     const int nslots = wh * ((ww + 15) >> 4);
 #pragma unroll
     for (int c = 32; c >= 8; c >>= 1)      // K = 128 / c chunks per thread, 4 slots per chunk round
@@ -603,11 +690,13 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
     row_slots = cts != 0;
   }
   // one dword per lane; the per-thread share of the window must fit the 32 prefetch registers (npix * cts <= 8192)
-  if (p.cts64 && cts == 0 && L.stride_c != 1 && nc >= 64 && npix <= 128 &&
+  if (p.cts64 && pairs && cts == 0 && nc >= 64 && (npix / 2) * 64 <= pair_budget &&
+      (long long)(npix + 1) * (64 + kLdsPad) + 64LL * bins <= avail) cts = 64;
+  if (p.cts64 && !pairs && cts == 0 && L.stride_c != 1 && nc >= 64 && npix <= 128 &&
       (long long)(npix + 1) * (64 + kLdsPad) + 64LL * bins <= avail) cts = 64;
 #pragma unroll
   for (int c = 32; c >= 8; c >>= 1)
-    if (cts == 0 && npix <= kLdsMaxPix && npix * c <= 8192 &&
+    if (cts == 0 && npix <= kLdsMaxPix * (pairs ? 2 : 1) && (pairs ? (npix / 2) * c <= pair_budget : npix * c <= 8192) &&
         (long long)(npix + 1) * (c + kLdsPad) + (long long)c * bins <= avail) cts = c;
   if (cts == 0) {
     // window too large for LDS: per-output gather straight from global (same arithmetic)
@@ -647,6 +736,21 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   if (row4) {
     StagerRow4<TIn> st; st.init(L, y0, xa, ng, wh, cts);
     run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out);
+  } else if (pairs) {
+    const int nkp = ceil_div(ceil_div(npix / 2, 16), kRoiAlignThreads / 64);
+#define DTC_RUN2(KK, GG) { StagerNCHW2<TIn, KK, GG> st; st.init(L, y0, x0, ww, wh, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
+    if constexpr (sizeof(TIn) == 2) {
+      if (cts == 64) DTC_RUN2(2, 16)
+      else if (nkp <= 4) DTC_RUN2(4, 8)
+      else if (nkp <= 8) DTC_RUN2(8, 4)
+      else DTC_RUN2(16, 2)
+    } else {
+      if (cts == 64) DTC_RUN2(1, 16)
+      else if (nkp <= 2) DTC_RUN2(2, 8)
+      else if (nkp <= 4) DTC_RUN2(4, 4)
+      else DTC_RUN2(8, 2)
+    }
+#undef DTC_RUN2
   } else if (L.stride_c == 1) {
     StagerNHWC<TIn> st; st.init(L, y0, x0, ww, wh, npix, cts);
     run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out);
@@ -1369,6 +1473,8 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   p.cts64 = getenv("DTC_RA_NO_CTS64") == nullptr;   // 64-channel sub-tiles for windows <= 128 px: +4 % on the bench workload
   // both measured (tools/tcp_probe_quad.sh): L1 accesses halve (187 M -> 91 M / 84 M per launch) but the line fills do not
   // change (51.8 M) and the launch gets slower (0.755 -> 0.788 / 0.869 ms): off by default, kept as tested A/B knobs
+  // 1: pixel-pair loads for 2-byte features; 2 (DTC_RA_PAIRS32=1): for fp32 features too (dwordx2 per lane)
+  p.pair_loads = getenv("DTC_RA_NO_PAIRS") != nullptr ? 0 : (getenv("DTC_RA_PAIRS32") != nullptr ? 2 : 1);
   p.quad_align = getenv("DTC_RA_QUAD") != nullptr;
   p.row_slots = getenv("DTC_RA_ROWSLOTS") != nullptr;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -179,7 +179,7 @@ def test_ordered_and_packed_entry_points(hip, oracle):
     assert np.array_equal(res[:200], ref) and not res[200].any()
 
 
-@pytest.mark.parametrize("env", ["DTC_ROIALIGN_WS", "DTC_ROIALIGN_DMA", "DTC_ROIALIGN_GENERAL", "DTC_RA_ROW4", "DTC_RA_NO_CTS64", "DTC_RA_QUAD", "DTC_RA_ROWSLOTS"])
+@pytest.mark.parametrize("env", ["DTC_ROIALIGN_WS", "DTC_ROIALIGN_DMA", "DTC_ROIALIGN_GENERAL", "DTC_RA_ROW4", "DTC_RA_NO_CTS64", "DTC_RA_QUAD", "DTC_RA_ROWSLOTS", "DTC_RA_PAIRS32"])
 def test_experimental_kernel_variants_bit_exact(hip, oracle, env, monkeypatch):
     """The env-selected RoIAlign variants kept in the library (wave-specialised loader/compute kernel, LDS-DMA staging, the
     general gather kernel) do the same arithmetic in the same order: bit-identical to the oracle, incl. channel tails."""
