@@ -12,7 +12,20 @@
 //     are formed with the same multiplies, roi_align_cpu_loop.cpp:95);
 //   * all FPN levels in one launch (per-RoI level id), output written directly in RoI order -- no cat / index_select
 //     (lib/model/detector.py:263-270);
-//   * element strides instead of a fixed NCHW layout, fp16 or fp32 features, fp32 accumulation.
+//   * element strides instead of a fixed NCHW layout, fp32 / fp16 / bf16 features, fp32 accumulation.
+//
+// Kernels in this file (all produce bit-identical results; tests/test_hip_roi_align.py runs every one against the oracle):
+//   roi_align_fwd_lds      DEFAULT for NCHW (and for channels_last with many taps per pixel): window staged in LDS through a
+//                          register prefetch pipeline; stagers StagerNCHW (dword per lane), StagerNCHW2 (pixel pairs, the
+//                          default for fp16/bf16), StagerNHWC, and the opt-in StagerRow4
+//   roi_align_fwd_nhwc     DEFAULT for channels_last features with few taps per pixel: taps gathered straight from L1/L2
+//   roi_align_fwd_general  per-output gather; oversize pooled sizes, and the reference implementation of the arithmetic
+//   roi_align_fwd_ws / roi_align_fwd_dma   measured-slower experiments (wave specialisation, LDS-DMA staging), opt-in
+// Environment knobs, read at every dispatch (A/B measurements and the variant tests; DESIGN.md section 3.1 has the numbers):
+//   DTC_ROIALIGN_GENERAL, DTC_ROIALIGN_NO_NHWC_DIRECT, DTC_ROIALIGN_WS, DTC_ROIALIGN_DMA   kernel selection
+//   DTC_ROIALIGN_LDS_KB (52)  DTC_RA_CHBLOCK (128)                                          workgroup shape
+//   DTC_RA_NO_XCD  DTC_RA_NO_CTS64  DTC_RA_NO_PAIRS                                         turn a default optimisation off
+//   DTC_RA_ROW4  DTC_RA_QUAD  DTC_RA_ROWSLOTS  DTC_RA_PAIRS32                                turn a measured-neutral/slower one on
 #include <stdlib.h>
 
 #include <type_traits>
