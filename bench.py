@@ -158,10 +158,12 @@ def main():
     def one_step():
         path.step(use_graph=not a.eager)
         if gather is not None:
-            gather.all_gather(path.dets, path.det_count)
+            gather.all_gather_async(path.dets, path.det_count)      # one packed collective per step, overlapped with the next
 
     for _ in range(a.warmup):
         one_step()
+    if gather is not None:
+        gather.finish()
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -169,6 +171,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_step()
+    if gather is not None:
+        gather.finish()                  # the last steps' collectives complete INSIDE the timed region
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()

@@ -41,3 +41,39 @@ class DetectionGatherer:
             dist.all_gather_into_tensor(self.all_dets, dets, group=self.group)
             dist.all_gather_into_tensor(self.all_counts, counts, group=self.group)
         return self.all_dets, self.all_counts
+
+    # ---- overlapped form: ONE collective per step, off the compute stream's critical path --------------------------------
+    # all_gather() above makes the compute stream wait for two latency-bound collectives before the next step can start.
+    # Here detections and counts are packed into one row per image ([max_out*6 + 1] floats; a count <= 2^24 is exact in
+    # float32), copied into one of two staging buffers on the compute stream, and gathered with async_op=True: the collective
+    # runs on the process group's own stream while the next step's kernels run, and a staging buffer is only waited for when
+    # it comes round again two steps later (or in finish()).
+    def all_gather_async(self, dets, counts):
+        if not hasattr(self, "_pack"):
+            per, width = dets.shape[0], dets.shape[1] * dets.shape[2] + 1
+            self._pack = [torch.zeros((per, width), dtype=torch.float32, device=dets.device) for _ in range(2)]
+            self._all = [torch.zeros((self.world, per, width), dtype=torch.float32, device=dets.device) for _ in range(2)]
+            self._work = [None, None]
+            self._turn = 0
+        s = self._turn
+        if self._work[s] is not None:
+            self._work[s].wait()                      # the gather that last used this staging buffer (two steps ago)
+        self._pack[s][:, :-1].copy_(dets.reshape(dets.shape[0], -1))
+        self._pack[s][:, -1].copy_(counts)
+        if dist.get_backend(self.group) == "gloo":
+            self._work[s] = dist.all_gather(list(self._all[s].unbind(0)), self._pack[s], group=self.group, async_op=True)
+        else:
+            self._work[s] = dist.all_gather_into_tensor(self._all[s], self._pack[s], group=self.group, async_op=True)
+        self._last = s
+        self._turn = 1 - s
+
+    def finish(self):
+        """Wait for the outstanding gathers; returns (all_dets [W,imgs,max_out,6], all_counts int32 [W,imgs]) of the last step."""
+        for w in self._work:
+            if w is not None:
+                w.wait()
+        self._work = [None, None]
+        a = self._all[self._last]
+        self.all_dets = a[:, :, :-1].reshape(self.all_dets.shape)
+        self.all_counts = a[:, :, -1].round().to(torch.int32)
+        return self.all_dets, self.all_counts

@@ -41,6 +41,11 @@ def _worker(rank, world, port, n_images, max_out, out_q):
         cnt[j] = n
     g = DetectionGatherer(per, max_out, torch.device("cpu"), world)
     all_d, all_c = g.all_gather(dets, cnt)
+    # the overlapped single-collective form bench.py uses must give the same answer, also after several steps in flight
+    for step in range(3):
+        g.all_gather_async(dets * float(step == 2), cnt * int(step == 2))
+    a_d, a_c = g.finish()
+    assert torch.equal(a_d, all_d) and torch.equal(a_c, all_c)
     order = unshard_order(n_images, world)
     flat_d = all_d.reshape(world * per, max_out, 6)[order]
     flat_c = all_c.reshape(world * per)[order]

@@ -1,0 +1,35 @@
+"""The RCCL leg of the multi-GPU path on the one GPU a test box has: a world-size-1 "nccl" (= RCCL on ROCm) process group
+running the same DetectionGatherer calls bench.py makes at N > 1 (blocking two-collective form and the overlapped packed
+form), so that the collective API usage is exercised on the real backend; the N = 2 semantics are covered on CPU by
+tests/test_dist_gloo.py.  -m gpu."""
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def test_detection_gatherer_over_rccl_world1():
+    from detectorch_amd.dist import DetectionGatherer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        g = DetectionGatherer(4, 16, dev, 1)
+        gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+        side = torch.cuda.Stream()
+        for step in range(5):
+            dets = torch.rand((4, 16, 6), generator=gen, device=dev)
+            cnt = torch.randint(0, 17, (4,), generator=gen, device=dev, dtype=torch.int32)
+            a, c = g.all_gather(dets, cnt)
+            assert torch.equal(a[0], dets) and torch.equal(c[0], cnt)
+            g.all_gather_async(dets, cnt)
+            dets2 = dets.clone()
+            dets.zero_()                                   # the next step overwrites the source: staging must have its copy
+        a, c = g.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(a[0], dets2) and torch.equal(c[0], cnt)
+    finally:
+        dist.destroy_process_group()
