@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--nhwc", action="store_true")
     ap.add_argument("--half", action="store_true")
     ap.add_argument("--sort", action="store_true", help="visit RoIs sorted by (image, level, y)")
+    ap.add_argument("--max-side", type=float, default=600.0, help="largest RoI side in pixels (48: every window <= ~14x14 on P2)")
     a = ap.parse_args()
     rs = synth.rng(3, 0)
     shapes = synth.fpn_level_shapes()[:4]
@@ -34,7 +35,7 @@ def main():
         feats = [f.half() for f in feats]
     if a.nhwc:
         feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
-    rois = np.concatenate([np.hstack([np.full((a.rois, 1), b, np.float32), synth.make_rois(rs, a.rois)])
+    rois = np.concatenate([np.hstack([np.full((a.rois, 1), b, np.float32), synth.make_rois(rs, a.rois, max_side=a.max_side)])
                            for b in range(a.batch)])
     lvn = fpn_level_of(rois[:, 1:])
     order = None
