@@ -144,3 +144,32 @@ def test_header_is_plain_c_and_cxx():
     subprocess.check_call(["g++", "-x", "c++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", hdr])
     code = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)          # declarations only (comments cite torch call sites)
     assert "torch" not in code.lower().replace("detectorch", "") and "#include <hip" not in code and "at::" not in code
+
+
+def test_prep_plan_host_logic_matches_oracle(oracle):
+    """dtc_prep_plan is pure host code (scale selection of blob.py:75-82, cv2's dsize rounding, im_list_to_blob's padded
+    shape): checked here without a GPU against the oracle restatement, incl. the long-side cap and half-way roundings."""
+    from detectorch_amd import hip
+    L = hip.lib()
+    sizes = [(500, 833), (480, 640), (640, 480), (400, 1000), (1000, 400), (333, 500), (801, 1333), (1, 1), (7, 2000), (1200, 1201)]
+    B = len(sizes)
+    hs = (ctypes.c_int32 * B)(*[h for h, _ in sizes]); ws = (ctypes.c_int32 * B)(*[w for _, w in sizes])
+    for (target, mx, stride) in [(800, 1333, 32), (800, 1333, 1), (600, 1000, 32), (64, 100, 32)]:
+        scales = (ctypes.c_double * B)(); out_hw = (ctypes.c_int32 * (2 * B))(); blob_hw = (ctypes.c_int32 * 2)()
+        assert L.dtc_prep_plan(hs, ws, B, target, mx, stride, scales, out_hw, blob_hw) == 0
+        mh = mw = 0
+        for k, (h, w) in enumerate(sizes):
+            s = oracle.lib().orc_prep_scale(h, w, target, mx)
+            assert scales[k] == s
+            oh, ow = max(int(np.round(h * s)), 1), max(int(np.round(w * s)), 1)
+            assert (out_hw[2 * k], out_hw[2 * k + 1]) == (oh, ow)
+            mh, mw = max(mh, oh), max(mw, ow)
+        if stride > 1:
+            mh, mw = -(-mh // stride) * stride, -(-mw // stride) * stride
+        assert (blob_hw[0], blob_hw[1]) == (mh, mw)
+    scales = (ctypes.c_double * 1)(); out_hw = (ctypes.c_int32 * 2)(); blob_hw = (ctypes.c_int32 * 2)()
+    assert L.dtc_prep_plan((ctypes.c_int32 * 1)(500), (ctypes.c_int32 * 1)(833), 1, 800, 1333, 32, scales, out_hw, blob_hw) == 0
+    assert scales[0] == 1.6 and (out_hw[0], out_hw[1]) == (800, 1333) and (blob_hw[0], blob_hw[1]) == (800, 1344)   # BASELINE input
+    assert L.dtc_prep_plan(None, None, 1, 800, 1333, 32, scales, out_hw, blob_hw) == -1
+    assert L.dtc_bbox_overlaps(None, -1, 4, None, 1, 4, None, None) == -1 and L.dtc_box_voting(None, 1, None, 9000, 0.5, None, None, None) == -1
+    assert L.dtc_mask_rle(None, 0, None, None, None, None, 1, 1, None, 1, None, None, 1, None, None) == -1
