@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 5 --warmup 2 --batch 8 --eager --no-cpu-baseline"
+CMD="python bench.py --steps 5 --warmup 2 --batch 8 --eager --no-cpu-baseline ${BENCH_ARGS:-}"   # BENCH_ARGS="--channels-last --fp16" etc.
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- $CMD > $OUT/stats.log 2>&1 < /dev/null
 # HBM-side traffic from the L2's fabric (EA) request counters, one counter group per run.  FETCH_SIZE itself is NOT used:
 # on gfx950 its expression prices every read request at 64 B (TCC_BUBBLE reads 0) while almost all requests are 128 B
