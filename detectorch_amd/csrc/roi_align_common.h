@@ -1,0 +1,107 @@
+// Shared device helpers of the RoIAlign kernels (roi_align.hip, roi_align_tile.hip): launch parameters, the XCD-aware
+// work assignment, and the RoI geometry of roi_align_forward_loop (lib/cppcuda_cffi/src/cpp/roi_align_cpu_loop.cpp:36-173)
+// restated operation for operation so that every kernel forms bit-identical sampling positions and weights.
+#pragma once
+#include "dtc_common.h"
+
+namespace dtc {
+
+struct RoiAlignParams {
+  dtc_feat_level lv[DTC_MAX_LEVELS];
+  const float* rois;
+  const int32_t* roi_levels;
+  const int32_t* roi_order;   // optional processing order: workgroup i handles RoI roi_order[i] (output row unchanged)
+  const float* roi_desc;      // optional packed descriptors [R,8] in VISITING order: (batch, x1, y1, x2, y2, level, out_row, 0)
+                              // one 32-byte load instead of three dependent global loads at the head of every workgroup
+  void* out;
+  int n_levels, channels, roi_cols, n_rois, pooled_h, pooled_w, sampling_ratio, ch_tile;
+  int ch_block;   // channels per workgroup of the LDS kernel (multiple of 64): setup (tables, window) is paid once per block
+  int quad_align; // 1: widen staged windows to 4-pixel boundaries (aligned lane quads; see roi_align_fwd_lds)
+  int row_slots;  // 1: row-slot chunk enumeration (a row piece belongs to one wave-instruction)
+  int pair_loads; // 1: 2-byte features are gathered as pixel pairs (StagerNCHW2)
+  int cts64;      // 1: allow 64-channel sub-tiles (one bin per ds_read_b128 lane group: conflict-free taps)
+  int row4;       // 1: 16-byte row pieces for NCHW levels whose rows are 4-element aligned (StagerRow4)
+  int xcd_remap;  // 1: workgroup -> work-item mapping keeps each XCD on a contiguous range of the visiting order
+};
+
+// XCD-aware work assignment.  The dispatcher deals workgroups round-robin over the 8 XCDs (workgroup b runs on XCD b % 8)
+// and each XCD has its own 4 MB L2.  RoIs are visited in (level, y) order so that neighbours share feature rows; with the
+// identity mapping those neighbours land on 8 different L2s and every feature line is pulled through the fabric once per
+// XCD that touches it.  Remapped, XCD x owns the contiguous slice [start(x), start(x+1)) of the visiting order and walks
+// it front to back: a line is fetched by one L2 (two at a slice boundary).  Bijective for any grid size.
+constexpr int kXcds = 8;
+__device__ __forceinline__ int xcd_work_item(int b, int n, int enabled) {
+  if (!enabled || n < 2 * kXcds) return b;
+  const int x = b % kXcds, j = b / kXcds;
+  const int q = n / kXcds, r = n - q * kXcds;
+  return x * q + min(x, r) + j;
+}
+
+// One axis of pre_calc_for_bilinear_interpolate (roi_align_cpu_loop.cpp:36-93).
+struct AxisEntry {
+  int lo, hi;   // element index along the axis (not yet multiplied by the stride)
+  float l, h;   // l = v - lo ; h = 1 - l.  Both forced to 0 for an out-of-range sample (its PreCalc is all-zero, :49-63)
+};
+
+__device__ __forceinline__ AxisEntry make_axis(float start, float bin, int p, int i, int grid, int extent) {
+  // :38-40  v = roi_start + p*bin + (i + .5f) * bin / grid     (float, left to right)
+  float v = start + (float)p * bin;
+  v = v + fdiv(((float)i + .5f) * bin, (float)grid);
+  bool valid = !(v < -1.0f || v > (float)extent);  // :49 (float vs double -1.0 compares identically)
+  if (v <= 0.f) v = 0.f;                           // :66-71
+  int lo = (int)v, hi;
+  if (lo >= extent - 1) { hi = lo = extent - 1; v = (float)lo; } else { hi = lo + 1; }  // :78-90
+  float l = v - (float)lo;                         // :92
+  float h = (float)(1.0 - (double)l);              // :94 "1. - ly": double subtract, rounded once to float
+  AxisEntry e;
+  e.lo = lo; e.hi = hi;
+  e.l = valid ? l : 0.f;
+  e.h = valid ? h : 0.f;
+  return e;
+}
+
+// What every workgroup derives from its RoI before touching features (roi_align_cpu_loop.cpp:143-173): which RoI / level /
+// image, the scaled box (NO rounding, :150-153), bin sizes, sampling grid and the divisor.
+struct RoiHead {
+  int r, lvl, b;              // output row, level index (< 0: padding row), image index
+  float sw, sh, rw, rh;       // scaled start (w, h) and size, size clamped to >= 1 (:160-161)
+  float bin_h, bin_w;         // :162-163
+  int gh, gw;                 // sampling grid (:166-170): fixed, or adaptive ceil(roi / pooled)
+  float count, inv_count;     // :173 ; inv_count != 0 when count is a power of two (x * inv_count == x / count exactly)
+};
+
+__device__ __forceinline__ RoiHead load_roi_head(const RoiAlignParams& p, int ri) {
+  RoiHead h;
+  float x1, y1, x2, y2;
+  h.b = 0;
+  if (p.roi_desc) {   // one packed 32-byte descriptor in visiting order
+    const float4 d0 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2];
+    const float4 d1 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2 + 1];
+    h.b = (int)d0.x; x1 = d0.y; y1 = d0.z; x2 = d0.w; y2 = d1.x; h.lvl = (int)d1.y; h.r = (int)d1.z;
+  } else {
+    h.r = p.roi_order ? p.roi_order[ri] : ri;
+    h.lvl = p.roi_levels ? p.roi_levels[h.r] : 0;
+    const float* roi = p.rois + (size_t)h.r * p.roi_cols;
+    if (p.roi_cols == 5) { h.b = (int)roi[0]; roi++; }          // :143-147
+    x1 = roi[0]; y1 = roi[1]; x2 = roi[2]; y2 = roi[3];
+  }
+  h.sw = h.sh = 0.f; h.rw = h.rh = 1.f; h.bin_h = h.bin_w = 1.f; h.gh = h.gw = 1; h.count = 1.f; h.inv_count = 1.f;
+  if (h.lvl < 0 || h.lvl >= p.n_levels) return h;
+  const float s = p.lv[h.lvl].spatial_scale;
+  h.sw = x1 * s; h.sh = y1 * s;
+  const float ew = x2 * s, eh = y2 * s;
+  h.rw = fmaxf(ew - h.sw, 1.f); h.rh = fmaxf(eh - h.sh, 1.f);
+  h.bin_h = fdiv(h.rh, (float)p.pooled_h); h.bin_w = fdiv(h.rw, (float)p.pooled_w);
+  h.gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(h.rh, (float)p.pooled_h));
+  h.gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(fdiv(h.rw, (float)p.pooled_w));
+  const int gg = h.gh * h.gw;
+  h.count = (float)gg;
+  h.inv_count = ((gg & (gg - 1)) == 0) ? fdiv(1.f, h.count) : 0.f;
+  return h;
+}
+
+// launchers of the cluster-stationary kernel (roi_align_tile.hip); in_dtype / out_dtype are DTC_* codes
+bool roi_align_tile_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
+int launch_roi_align_tile(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream);
+
+}  // namespace dtc

@@ -1,0 +1,436 @@
+// A1  RoIAlign forward for gfx950 -- CLUSTER-STATIONARY kernel (sampling_ratio == 2: the FPN box and mask heads).
+//
+// Replaces roi_align_forward_kernel (lib/cppcuda/roi_align_forward_cuda.cu:82-159) and is bit-compatible with the CPU path
+// roi_align_forward_loop (lib/cppcuda_cffi/src/cpp/roi_align_cpu_loop.cpp:118-219): same float32 operations, same order.
+//
+// Why this shape.  With NCHW features a RoI's window is a stack of short row pieces (12 pixels = 48 B on P2) cut out of
+// 128-byte lines, once per channel.  A vector L1 keeps at most ~64 line fills in flight, so a CU moves 8 KB per memory
+// latency whatever the kernel does with the bytes: the launch time is (line fills) x (latency) / 64 per CU, and a
+// RoI-stationary workgroup (roi_align_fwd_lds in roi_align.hip) spends 16.5 fills per (RoI, channel) where 2.2 are
+// compulsory -- measured 52 M fills / 0.52 ms per 8000-RoI launch, with every staging variant (round 1).
+// RoIs that are neighbours in the visiting order of dtc_fpn_collect_distribute (level, row band, x) overlap about two-fold
+// and sit side by side, so here a workgroup owns K consecutive RoIs of that order:
+//   1. their windows are merged greedily into clusters while the merge does not ADD lines (rows x (bytes + 128)) and the
+//      union fits the LDS window -- a cluster's rows are 150-250 B wide instead of 48 B, i.e. every fetched line is mostly used;
+//   2. the cluster's union window is staged ONCE per channel quad with 16-byte row-piece loads (4 pixels of one channel),
+//      issue-early / write-late through registers, into an LDS image [quad][pixel][4 channels];
+//   3. lane <-> (RoI, bin): sampling positions and weights are formed ONCE per lane (registers), then every channel quad
+//      costs 16 ds_read_b128 + the reference's multiply-adds, and the four results go straight to the [R,C,PH,PW] output
+//      (lanes of consecutive bins -> 196-byte runs; no LDS transposition slab, no table lookups in the loop).
+// The LDS image is padded by one pixel slot every 8 pixels (phys = px + px/8): the transposing ds_write_b32 of 16
+// consecutive 4-pixel groups x 2 channels then spread over all 32 banks two-way (free for ds_write_b32) instead of eight-way.
+//
+// Anything the cluster path does not cover takes a correct slow path inside the same kernel: levels whose rows are not
+// 16-byte aligned (P5: 42 columns) are staged with clamped scalar loads; a single RoI whose window exceeds the LDS image
+// is gathered per output straight from global memory; padding rows (level < 0) are zero-filled.
+#include <stdlib.h>
+
+#include <mutex>
+
+#include "roi_align_common.h"
+
+namespace dtc {
+
+constexpr int kTileMaxK = 32;                       // RoIs per workgroup (upper bound of the K the host picks)
+constexpr int kTileHdrBytes = 2 * kTileMaxK * 32 + 16;
+// Workgroup shapes (threads, 16-byte row pieces a thread carries per pass, waves per SIMD the register budget allows):
+//   256 threads x 8 pieces, 3 workgroups / CU (<= 168 VGPRs, 52 KB LDS each)   K = 5 RoIs of 7x7 bins per workgroup
+//   512 threads x 4 pieces, 2 workgroups / CU (<= 128 VGPRs, 78 KB)            K = 10
+//  1024 threads x 4 pieces, 1 workgroup  / CU (<= 128 VGPRs, 156 KB)           K = 20
+template <int NT> struct TileShape;
+template <> struct TileShape<256> { static constexpr int kUnits = 8, kWaves = 3, kLdsKB = 52; };
+template <> struct TileShape<512> { static constexpr int kUnits = 4, kWaves = 4, kLdsKB = 78; };
+template <> struct TileShape<1024> { static constexpr int kUnits = 4, kWaves = 4, kLdsKB = 156; };
+
+struct TileRoi { int lvl, b, x0, x1, y0, y1, r, valid; };            // window in feature pixels of its level, inclusive
+struct TileGroup { int first, count, kind, x0, x1, y0, y1, pad; };   // kind 0: pooled cluster, 1: zero rows, 2: absent, 3: oversize
+enum { kGrpPool = 0, kGrpZero = 1, kGrpAbsent = 2, kGrpGather = 3 };
+
+template <typename TIn> struct Piece4;
+template <> struct Piece4<float> {
+  static __device__ __forceinline__ float4 ld(const char* p) { return *reinterpret_cast<const float4*>(p); }
+};
+template <> struct Piece4<__half> {
+  static __device__ __forceinline__ float4 ld(const char* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    const __half2 a = *reinterpret_cast<const __half2*>(&r.x), b = *reinterpret_cast<const __half2*>(&r.y);
+    return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
+  }
+};
+template <> struct Piece4<bf16_t> {
+  static __device__ __forceinline__ float4 ld(const char* p) { return bf16x4_to_f32(*reinterpret_cast<const uint2*>(p)); }
+};
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// LDS slot (16-byte units: one pixel x 4 channels) of window pixel px inside one quad image: one pad slot every 8 pixels
+__device__ __forceinline__ int tile_phys(int px) { return px + (px >> 3); }
+
+// Everything a lane needs to pool ITS (RoI, bin) from the LDS image, formed once per cluster.
+struct TileItem {
+  int a[2][2][4];           // [iy][ix][tap]: LDS byte offsets (inside a quad image) of (y.lo,x.lo) (y.lo,x.hi) (y.hi,x.lo) (y.hi,x.hi)
+  float yl[2], yh[2], xl[2], xh[2];
+  bool on;
+};
+
+// One cluster: stage + pool every channel quad of this workgroup's channel block.
+// Register pipeline: a thread carries up to kTileUnits 16-byte row pieces per pass; unit u = q * KC + i is piece-chunk i
+// (16 consecutive pieces x 4 channels per wave-instruction) of channel quad q, so a pass stages nq_pass quads with
+// KC * nq_pass <= kTileUnits.  All loads of pass n+1 are issued before pass n is pooled and written to LDS after it.
+template <typename TIn, typename TOut, int NT>
+__device__ __forceinline__ void tile_passes(const dtc_feat_level& L, const TIn* fbase, int nc, int bins, float* win,
+                                            int plane, int nq_pass, int y0, int x0a, int ngx, int npos, bool vec,
+                                            const TileItem& it, TOut* ob) {
+  constexpr int NW = NT / 64;
+  constexpr int U = TileShape<NT>::kUnits;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, cl = (lane >> 4) & 3;
+  const int nchunk = (npos + 15) >> 4;
+  const int KC = ceil_div(nchunk, NW);
+  const float rinv = 1.0f / (float)ngx;
+  const int nq_tot = ceil_div(nc, 4);
+  uint32_t uoff[U];     // byte offset of the unit's piece (row, 4 pixels, channel 4q + cl) from the pass base plane
+  int ulds[U];          // float index of (first pixel of the piece, channel cl) in the LDS image
+  if (vec) {
+    const int sh32 = (int)L.stride_h, sc32 = (int)L.stride_c;
+    int q = 0, i = 0;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int pos = min((wv + i * NW) * 16 + pl, npos - 1);    // lanes past the window duplicate its last piece (same bytes)
+      const int row = (int)(((float)pos + 0.5f) * rinv);         // exact: pos < 2^13, distance to an integer >= 0.5 / ngx
+      const int gx = pos - row * ngx;
+      // 32-bit arithmetic throughout (vec guarantees the offsets fit): keeps the loads in SGPR-base + 32-bit-lane-offset form
+      uoff[u] = (uint32_t)((y0 + row) * sh32 + (x0a + 4 * gx) + (4 * q + cl) * sc32) * (uint32_t)sizeof(TIn);
+      ulds[u] = q * plane * 4 + ((4 * pos + (pos >> 1)) << 2) + cl;
+      if (++i == KC) { i = 0; q++; }
+    }
+  }
+  float4 v[U];
+  auto issue = [&](int cs) {      // vec only: every staged channel exists (nc % 4 == 0) and rows are 16-byte aligned
+    const int nu = KC * min(nq_pass, nq_tot - (cs >> 2));
+    // uniform base (SGPR pair) + 32-bit lane offset; uni() hides the pass offset from loop strength reduction, which would
+    // otherwise turn every unit into its own 64-bit pointer induction variable (16 VGPRs)
+    const char* base = reinterpret_cast<const char*>(fbase + (int64_t)uni(cs) * L.stride_c);
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (u < nu) {
+        uint32_t o = uoff[u];
+        asm volatile("" : "+v"(o));       // keep the zero-extension next to the load (a hoisted one costs a second VGPR per unit)
+        v[u] = Piece4<TIn>::ld(base + o);
+      }
+  };
+  auto commit = [&](int cs) {
+    const int nu = KC * min(nq_pass, nq_tot - (cs >> 2));
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (u < nu) {
+        float* d = win + ulds[u];
+        d[0] = v[u].x; d[4] = v[u].y; d[8] = v[u].z; d[12] = v[u].w;
+      }
+  };
+  // Rows that are not 16-byte aligned, strided columns or a channel tail (P5's 42 columns, odd maps, C % 4 != 0): no
+  // register pipeline, each piece is four clamped scalar loads written straight to LDS.  Correct for any strides.
+  auto stage_scalar = [&](int cs) {
+#pragma unroll 1
+    for (int q = 0; q < nq_pass; q++) {
+      const int cq = cs + 4 * q;
+      if (cq >= nc) break;
+      const int cle = min(cl, nc - 1 - cq);                        // channel tail: clamp the plane, never stored
+      const TIn* base = fbase + (int64_t)(cq + cle) * L.stride_c;
+#pragma unroll 1
+      for (int t = wv; t < nchunk; t += NW) {
+        const int pos = min(t * 16 + pl, npos - 1);
+        const int row = (int)(((float)pos + 0.5f) * rinv);
+        const int gx = pos - row * ngx;
+        const int rem = L.width - 1 - (x0a + 4 * gx);               // >= 0: a piece starts inside the map
+        const TIn* s = base + (int64_t)(y0 + row) * L.stride_h + (int64_t)(x0a + 4 * gx) * L.stride_w;
+        float* d = win + q * plane * 4 + ((4 * pos + (pos >> 1)) << 2) + cl;
+        d[0] = to_f32<TIn>(s[0]);
+        d[4] = to_f32<TIn>(s[(int64_t)min(1, rem) * L.stride_w]);
+        d[8] = to_f32<TIn>(s[(int64_t)min(2, rem) * L.stride_w]);
+        d[12] = to_f32<TIn>(s[(int64_t)min(3, rem) * L.stride_w]);
+      }
+    }
+  };
+
+  if (vec) issue(0);
+#pragma unroll 1
+  for (int qs = 0; qs < nq_tot; qs += nq_pass) {
+    const int cs = 4 * qs;
+    const int nq_cur = min(nq_pass, nq_tot - qs);
+    if (vec) commit(cs); else stage_scalar(cs);
+    __syncthreads();
+    if (vec && qs + nq_pass < nq_tot) issue(cs + 4 * nq_pass);    // next pass: in flight (registers) while this one is pooled
+    if (it.on) {
+#pragma unroll 1
+      for (int q = 0; q < nq_cur; q++) {
+        // uniform quad offset, opaque to the optimiser: otherwise every tap address becomes its own induction variable
+        const char* wq = reinterpret_cast<const char*>(win) + uni(q * plane * 16);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        // reference order: for iy { for ix { acc += w1*v1 + w2*v2 + w3*v3 + w4*v4 } }   (roi_align_cpu_loop.cpp:203-214)
+#pragma unroll
+        for (int iy = 0; iy < 2; iy++) {
+          float4 t[2][4];
+#pragma unroll
+          for (int ix = 0; ix < 2; ix++)
+#pragma unroll
+            for (int k = 0; k < 4; k++)                                       // 8 ds_read_b128 in flight per sample row
+              t[ix][k] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(wq + it.a[iy][ix][k], 16));
+#pragma unroll
+          for (int ix = 0; ix < 2; ix++) {
+            const float w1 = it.yh[iy] * it.xh[ix], w2 = it.yh[iy] * it.xl[ix];               // roi_align_cpu_loop.cpp:95
+            const float w3 = it.yl[iy] * it.xh[ix], w4 = it.yl[iy] * it.xl[ix];
+            a0 += w1 * t[ix][0].x + w2 * t[ix][1].x + w3 * t[ix][2].x + w4 * t[ix][3].x;        // :208-211
+            a1 += w1 * t[ix][0].y + w2 * t[ix][1].y + w3 * t[ix][2].y + w4 * t[ix][3].y;
+            a2 += w1 * t[ix][0].z + w2 * t[ix][1].z + w3 * t[ix][2].z + w4 * t[ix][3].z;
+            a3 += w1 * t[ix][0].w + w2 * t[ix][1].w + w3 * t[ix][2].w + w4 * t[ix][3].w;
+          }
+          __builtin_amdgcn_sched_barrier(0);      // keep the two sample rows apart: 32, not 64, tap registers live
+        }
+        // :216  output_val /= count ; count == 4 -> x * 0.25f is the same float32
+        const int c = cs + 4 * q;                 // uniform
+        TOut* o = ob + (size_t)c * bins;
+        o[0] = from_f32<TOut>(a0 * 0.25f);
+        if (c + 1 < nc) o[bins] = from_f32<TOut>(a1 * 0.25f);
+        if (c + 2 < nc) o[2 * bins] = from_f32<TOut>(a2 * 0.25f);
+        if (c + 3 < nc) o[3 * bins] = from_f32<TOut>(a3 * 0.25f);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename TIn, typename TOut, int NT>
+__global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  TileRoi* troi = reinterpret_cast<TileRoi*>(smem);
+  TileGroup* tgrp = reinterpret_cast<TileGroup*>(smem + kTileMaxK * 32);
+  int* ngp = reinterpret_cast<int*>(smem + 2 * kTileMaxK * 32);
+  float* win = reinterpret_cast<float*>(smem + kTileHdrBytes);
+  const int win_bytes = lds_bytes - kTileHdrBytes;
+  constexpr int NW = NT / 64;
+  constexpr int kMaxPos = TileShape<NT>::kUnits * NW * 16;                  // 16-byte pieces the register pipeline can carry per quad
+  const int tid = threadIdx.x;
+  const int nct = ceil_div(p.channels, p.ch_block);
+  const int wi = xcd_work_item(blockIdx.x, gridDim.x, p.xcd_remap);
+  const int grp = wi / nct;
+  const int c0 = (wi - grp * nct) * p.ch_block;
+  const int nc = min(p.ch_block, p.channels - c0);
+  const int bins = p.pooled_h * p.pooled_w;
+  const int K = kgroup;
+
+  // ---- A. windows of this workgroup's K RoIs (lane k) -----------------------------------------------------------------
+  if (tid < K) {
+    TileRoi t;
+    t.lvl = -1; t.b = 0; t.x0 = t.x1 = t.y0 = t.y1 = 0; t.r = 0; t.valid = 0;
+    const int ri = grp * K + tid;
+    if (ri < p.n_rois) {
+      const RoiHead hd = load_roi_head(p, ri);
+      t.valid = 1; t.r = hd.r; t.b = hd.b;
+      if (hd.lvl >= 0 && hd.lvl < p.n_levels) {
+        t.lvl = hd.lvl;
+        const int H = p.lv[hd.lvl].height, W = p.lv[hd.lvl].width;
+        // sample positions are non-decreasing in (bin, sample): first .lo / last .hi bound the window (roi_align_cpu_loop.cpp:38-90)
+        t.y0 = make_axis(hd.sh, hd.bin_h, 0, 0, 2, H).lo;
+        t.y1 = make_axis(hd.sh, hd.bin_h, p.pooled_h - 1, 1, 2, H).hi;
+        t.x0 = make_axis(hd.sw, hd.bin_w, 0, 0, 2, W).lo;
+        t.x1 = make_axis(hd.sw, hd.bin_w, p.pooled_w - 1, 1, 2, W).hi;
+      }
+    }
+    troi[tid] = t;
+  }
+  __syncthreads();
+
+  // ---- B. greedy clustering along the visiting order (one lane; K <= 32 steps) ----------------------------------------
+  if (tid == 0) {
+    const int esz = (int)sizeof(TIn);
+    int ng = 0, k = 0;
+    while (k < K) {
+      const TileRoi a = troi[k];
+      TileGroup g;
+      g.first = k; g.count = 1; g.x0 = a.x0; g.x1 = a.x1; g.y0 = a.y0; g.y1 = a.y1; g.pad = 0;
+      if (!a.valid) g.kind = kGrpAbsent;
+      else if (a.lvl < 0) g.kind = kGrpZero;
+      else {
+        const int ngx0 = (a.x1 >> 2) - (a.x0 >> 2) + 1, th0 = a.y1 - a.y0 + 1, npos0 = th0 * ngx0;
+        if (npos0 > kMaxPos || (4 * npos0 + (npos0 >> 1) + 1) * 16 > win_bytes || bins > NT) {
+          g.kind = kGrpGather;
+        } else {
+          g.kind = kGrpPool;
+          long long cost = (long long)th0 * ((a.x1 - a.x0 + 1) * esz + 128);
+          while (k + g.count < K && (g.count + 1) * bins <= NT) {
+            const TileRoi n = troi[k + g.count];
+            if (!n.valid || n.lvl != a.lvl || n.b != a.b) break;
+            const int ux0 = min(g.x0, n.x0), ux1 = max(g.x1, n.x1), uy0 = min(g.y0, n.y0), uy1 = max(g.y1, n.y1);
+            const int ungx = (ux1 >> 2) - (ux0 >> 2) + 1, uth = uy1 - uy0 + 1, unpos = uth * ungx;
+            if (unpos > kMaxPos || (4 * unpos + (unpos >> 1) + 1) * 16 > win_bytes) break;
+            const long long ucost = (long long)uth * ((ux1 - ux0 + 1) * esz + 128);
+            const long long ncost = (long long)(n.y1 - n.y0 + 1) * ((n.x1 - n.x0 + 1) * esz + 128);
+            if (ucost > cost + ncost) break;                       // merging would fetch more lines than it saves
+            g.x0 = ux0; g.x1 = ux1; g.y0 = uy0; g.y1 = uy1; g.count++;
+            cost = ucost;
+          }
+        }
+      }
+      tgrp[ng++] = g;
+      k += g.count;
+    }
+    *ngp = ng;
+  }
+  __syncthreads();
+
+  // ---- C. clusters ----------------------------------------------------------------------------------------------------
+  const int ngroups = uni(*ngp);
+  for (int gi = 0; gi < ngroups; gi++) {
+    const int first = uni(tgrp[gi].first), count = uni(tgrp[gi].count), kind = uni(tgrp[gi].kind);
+    if (kind == kGrpAbsent) continue;
+    if (kind == kGrpZero) {    // padding row of a fixed-shape batch (fpn.hip emits level -1): defined output
+      TOut* oz = reinterpret_cast<TOut*>(p.out) + ((size_t)uni(troi[first].r) * p.channels + c0) * bins;
+      for (int o = tid; o < nc * bins; o += NT) oz[o] = from_f32<TOut>(0.f);
+      continue;
+    }
+    const int lvl = uni(troi[first].lvl), b = uni(troi[first].b);
+    const dtc_feat_level L = p.lv[lvl];
+    const TIn* fbase = reinterpret_cast<const TIn*>(L.data) + (int64_t)b * L.stride_n + (int64_t)c0 * L.stride_c;
+    if (kind == kGrpGather) {
+      // a single window larger than the LDS image: per-output gather straight from global memory, geometry on the fly
+      const RoiHead hd = load_roi_head(p, grp * K + first);
+      TOut* og = reinterpret_cast<TOut*>(p.out) + ((size_t)hd.r * p.channels + c0) * bins;
+      for (int o = tid; o < nc * bins; o += NT) {
+        const int c = o / bins, bin = o - c * bins;
+        const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
+        const TIn* d = fbase + (int64_t)c * L.stride_c;
+        float acc = 0.f;
+        for (int iy = 0; iy < 2; iy++) {
+          const AxisEntry y = make_axis(hd.sh, hd.bin_h, ph, iy, 2, L.height);
+          const int64_t ylo = (int64_t)y.lo * L.stride_h, yhi = (int64_t)y.hi * L.stride_h;
+          for (int ix = 0; ix < 2; ix++) {
+            const AxisEntry x = make_axis(hd.sw, hd.bin_w, pw, ix, 2, L.width);
+            const int64_t xlo = (int64_t)x.lo * L.stride_w, xhi = (int64_t)x.hi * L.stride_w;
+            const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;
+            acc += w1 * to_f32<TIn>(d[ylo + xlo]) + w2 * to_f32<TIn>(d[ylo + xhi]) + w3 * to_f32<TIn>(d[yhi + xlo]) +
+                   w4 * to_f32<TIn>(d[yhi + xhi]);
+          }
+        }
+        og[o] = from_f32<TOut>(acc * 0.25f);
+      }
+      continue;
+    }
+    // cluster geometry (uniform)
+    const int gx0 = uni(tgrp[gi].x0), gx1 = uni(tgrp[gi].x1), gy0 = uni(tgrp[gi].y0), gy1 = uni(tgrp[gi].y1);
+    const int x0a = gx0 & ~3;
+    const int ngx = (gx1 >> 2) - (gx0 >> 2) + 1;
+    const int tw = 4 * ngx, th = gy1 - gy0 + 1, npos = th * ngx;
+    const int plane = 4 * npos + (npos >> 1) + 1;           // slots per quad image
+    const bool vec = L.stride_w == 1 && ((L.width | L.stride_h | L.stride_c | L.stride_n | nc | c0) & 3) == 0 &&
+                     (reinterpret_cast<uintptr_t>(L.data) & (4 * sizeof(TIn) - 1)) == 0 && L.stride_h > 0 && L.stride_c > 0 &&
+                     L.stride_h * L.height + L.stride_c * 4 * TileShape<NT>::kUnits < (1ll << 28);     // lane offsets fit 32 bits
+    const int KC = ceil_div((npos + 15) >> 4, NW);
+    // ---- the lane's item -------------------------------------------------------------------------------------------
+    const int n_it = count * bins;
+    TileItem it;
+    it.on = tid < n_it;
+    const int itx = it.on ? tid : 0;
+    const int kk = first + itx / bins, bin = itx % bins;
+    const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
+    const RoiHead hd = load_roi_head(p, grp * K + kk);
+    int ylo[2], yhi[2], xlo[2], xhi[2];      // window-relative: rows premultiplied by the window width
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const AxisEntry ey = make_axis(hd.sh, hd.bin_h, ph, i, 2, L.height);
+      const AxisEntry ex = make_axis(hd.sw, hd.bin_w, pw, i, 2, L.width);
+      it.yl[i] = ey.l; it.yh[i] = ey.h; it.xl[i] = ex.l; it.xh[i] = ex.h;
+      ylo[i] = (ey.lo - gy0) * tw; yhi[i] = (ey.hi - gy0) * tw;
+      xlo[i] = ex.lo - x0a; xhi[i] = ex.hi - x0a;
+    }
+#pragma unroll
+    for (int iy = 0; iy < 2; iy++)
+#pragma unroll
+      for (int ix = 0; ix < 2; ix++) {
+        int t0 = tile_phys(ylo[iy] + xlo[ix]) << 4, t1 = tile_phys(ylo[iy] + xhi[ix]) << 4;
+        int t2 = tile_phys(yhi[iy] + xlo[ix]) << 4, t3 = tile_phys(yhi[iy] + xhi[ix]) << 4;
+        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));   // one finished VGPR per tap: do not re-derive in the loop
+        it.a[iy][ix][0] = t0; it.a[iy][ix][1] = t1; it.a[iy][ix][2] = t2; it.a[iy][ix][3] = t3;
+      }
+    TOut* ob = reinterpret_cast<TOut*>(p.out) + ((size_t)hd.r * p.channels + c0) * bins + bin;
+    const int nq_pass = max(1, min(min(win_bytes / (plane * 16), TileShape<NT>::kUnits / KC), ceil_div(nc, 4)));
+    tile_passes<TIn, TOut, NT>(L, fbase, nc, bins, win, plane, nq_pass, gy0, x0a, ngx, npos, vec, it, ob);
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+struct TileConfig {
+  int nt = 256;        // threads per workgroup: 256 | 512 | 1024
+  int lds_kb = 0;      // LDS per workgroup (0: TileShape<NT>::kLdsKB)
+  int k = 0;           // RoIs per workgroup (0: threads / bins)
+  int ch_block = 0;    // channels per workgroup (0: chosen per launch)
+};
+static const TileConfig& tile_config() {   // development knobs, resolved ONCE (thread-safe static initialisation)
+  static const TileConfig cfg = [] {
+    TileConfig c;
+    if (const char* e = getenv("DTC_RA_TILE_NT")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) c.nt = v; }
+    if (const char* e = getenv("DTC_RA_TILE_LDS_KB")) { const int v = atoi(e); if (v >= 8 && v <= 160) c.lds_kb = v; }
+    if (const char* e = getenv("DTC_RA_TILE_K")) { const int v = atoi(e); if (v >= 1 && v <= kTileMaxK) c.k = v; }
+    if (const char* e = getenv("DTC_RA_TILE_CHBLOCK")) { const int v = atoi(e); if (v >= 4 && (v & 3) == 0) c.ch_block = v; }
+    return c;
+  }();
+  return cfg;
+}
+
+template <typename TIn, typename TOut, int NT>
+static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
+  const TileConfig& cfg = tile_config();
+  const int bins = p.pooled_h * p.pooled_w;
+  int K = cfg.k ? cfg.k : NT / bins;
+  K = K < 1 ? 1 : (K > kTileMaxK ? kTileMaxK : K);
+  if (K * bins > NT) K = NT / bins;
+  if (K < 1) return DTC_EUNSUPPORTED;
+  const int lds_b = (cfg.lds_kb ? cfg.lds_kb : TileShape<NT>::kLdsKB) * 1024;
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_tile<TIn, TOut, NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  if (attr_rc != hipSuccess) return DTC_ELAUNCH;
+  const int ngrp = ceil_div(p.n_rois, K);
+  // channels per workgroup: the per-cluster setup (geometry, item registers) is paid once per block; keep >= ~4 workgroups per CU
+  int cb = cfg.ch_block ? cfg.ch_block : 128;
+  while (cb > 32 && (long long)ngrp * ceil_div(p.channels, cb) < 2048) cb >>= 1;
+  p.ch_block = cb;
+  p.xcd_remap = 1;
+  const int nct = ceil_div(p.channels, p.ch_block);
+  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b);
+  DTC_CHECK_LAUNCH();
+  return DTC_OK;
+}
+
+template <typename TIn, typename TOut>
+static int launch_tile_t(const RoiAlignParams& p, hipStream_t stream) {
+  switch (tile_config().nt) {
+    case 512: return launch_tile_nt<TIn, TOut, 512>(p, stream);
+    case 1024: return launch_tile_nt<TIn, TOut, 1024>(p, stream);
+    default: return launch_tile_nt<TIn, TOut, 256>(p, stream);
+  }
+}
+
+bool roi_align_tile_supported(const RoiAlignParams& p, int in_dtype, int out_dtype) {
+  if (p.sampling_ratio != 2) return false;
+  if (p.pooled_h * p.pooled_w > tile_config().nt) return false;
+  const bool f = in_dtype == DTC_F32, h = in_dtype == DTC_F16, b = in_dtype == DTC_BF16;
+  return (f && (out_dtype == DTC_F32 || out_dtype == DTC_F16 || out_dtype == DTC_BF16)) ||
+         (h && (out_dtype == DTC_F32 || out_dtype == DTC_F16)) || (b && (out_dtype == DTC_F32 || out_dtype == DTC_BF16));
+}
+
+int launch_roi_align_tile(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream) {
+  if (p.n_rois == 0) return DTC_OK;
+  if (in_dtype == DTC_F32 && out_dtype == DTC_F32) return launch_tile_t<float, float>(p, stream);
+  if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return launch_tile_t<__half, float>(p, stream);
+  if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return launch_tile_t<__half, __half>(p, stream);
+  if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return launch_tile_t<float, __half>(p, stream);
+  if (in_dtype == DTC_BF16 && out_dtype == DTC_F32) return launch_tile_t<bf16_t, float>(p, stream);
+  if (in_dtype == DTC_BF16 && out_dtype == DTC_BF16) return launch_tile_t<bf16_t, bf16_t>(p, stream);
+  if (in_dtype == DTC_F32 && out_dtype == DTC_BF16) return launch_tile_t<float, bf16_t>(p, stream);
+  return DTC_EUNSUPPORTED;
+}
+
+}  // namespace dtc

@@ -75,3 +75,25 @@ def test_overlapped_split_equals_single(oracle):
     for b in range(B):
         n = min(int(one.det_count[b]), one.max_out)
         assert torch.equal(one.dets[b, :n], two.dets[b, :n])
+
+
+def test_bench_configuration_vs_oracle_chain(oracle):
+    """The exact configuration bench.py times -- seed 3000, batch 8, C = 256, hipGraph replay -- against the oracle chain for
+    the first and the last image of the batch (every intermediate bit-exact, incl. the 8000-RoI box-head RoIAlign launch)."""
+    import chain
+    from detectorch_amd.pipeline import FpnRegionPath, synthetic_batch
+    dev = torch.device("cuda", 0)
+    B = 8
+    path = FpnRegionPath(B, dev)
+    inputs = synthetic_batch(B, dev, seed=3000)
+    path.bind(*inputs)
+    path.step(use_graph=True)
+    path.step(use_graph=True)
+    torch.cuda.synchronize()
+    rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, sf, im_size = inputs
+    host = lambda t: t.float().cpu().numpy()
+    for b in (0, B - 1):
+        ref = chain.fpn_hot_path([host(c[b]) for c in rpn_cls], [host(d[b]) for d in rpn_bbox], [host(f[b:b + 1]) for f in feats],
+                                 host(cls_score[b]), host(bbox_pred[b]), host(masks[b * path.max_out:(b + 1) * path.max_out]),
+                                 float(sf[b]), host(im_size[b]), path.pad_h, path.pad_w)
+        assert chain.compare_with_gpu(path, b, ref, int(im_size[b, 0]), int(im_size[b, 1]))

@@ -25,7 +25,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--nhwc", action="store_true")
     ap.add_argument("--half", action="store_true")
-    ap.add_argument("--sort", action="store_true", help="visit RoIs sorted by (image, level, y)")
+    ap.add_argument("--sort", action="store_true", help="visit RoIs sorted by (image, level, row band, x) like dtc_fpn_collect_distribute")
+    ap.add_argument("--band-log2", type=int, default=int(os.environ.get("DTC_FPN_BAND_LOG2", "5")))
     ap.add_argument("--max-side", type=float, default=600.0, help="largest RoI side in pixels (48: every window <= ~14x14 on P2)")
     a = ap.parse_args()
     rs = synth.rng(3, 0)
@@ -40,8 +41,9 @@ def main():
     lvn = fpn_level_of(rois[:, 1:])
     order = None
     if a.sort:
-        yc = (rois[:, 2] + rois[:, 4]) * 0.5
-        order = torch.from_numpy(np.lexsort((yc, lvn, rois[:, 0])).astype(np.int32)).cuda()
+        yc, xc = (rois[:, 2] + rois[:, 4]) * 0.5, (rois[:, 1] + rois[:, 3]) * 0.5
+        band = (yc / (4.0 * 2.0 ** lvn * (1 << a.band_log2))).astype(np.int32)       # 2^band_log2 feature rows of the level
+        order = torch.from_numpy(np.lexsort((xc, band, lvn, rois[:, 0])).astype(np.int32)).cuda()
     lv = torch.from_numpy(lvn).cuda()
     print("level histogram:", np.bincount(lv.cpu().numpy(), minlength=4))
     rois = torch.from_numpy(rois).cuda()
