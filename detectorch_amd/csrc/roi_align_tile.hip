@@ -46,19 +46,35 @@ struct TileRoi { int lvl, b, x0, x1, y0, y1, r, valid; };            // window i
 struct TileGroup { int first, count, kind, x0, x1, y0, y1, pad; };   // kind 0: pooled cluster, 1: zero rows, 2: absent, 3: oversize
 enum { kGrpPool = 0, kGrpZero = 1, kGrpAbsent = 2, kGrpGather = 3 };
 
+// 16-byte (fp32) / 8-byte (fp16, bf16) row pieces through raw buffer loads: SGPR resource (base of this cluster's image /
+// channel block) + 32-bit lane offset + SGPR pass offset -- no 64-bit address registers, and dword alignment is enough
+// (rows of a level whose width is not a multiple of 4, P5's 42 columns, are read with the same instruction).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base) {
+  // raw buffer, no bounds clamp (num_records = 2^32 - 1); word 3 = DATA_FORMAT 32 (the gfx9 raw-buffer encoding)
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000);
+}
 template <typename TIn> struct Piece4;
 template <> struct Piece4<float> {
-  static __device__ __forceinline__ float4 ld(const char* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ float4 ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  }
 };
 template <> struct Piece4<__half> {
-  static __device__ __forceinline__ float4 ld(const char* p) {
-    const uint2 r = *reinterpret_cast<const uint2*>(p);
-    const __half2 a = *reinterpret_cast<const __half2*>(&r.x), b = *reinterpret_cast<const __half2*>(&r.y);
+  static __device__ __forceinline__ float4 ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    const uint32_t x = v.x, y = v.y;
+    const __half2 a = *reinterpret_cast<const __half2*>(&x), b = *reinterpret_cast<const __half2*>(&y);
     return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
   }
 };
 template <> struct Piece4<bf16_t> {
-  static __device__ __forceinline__ float4 ld(const char* p) { return bf16x4_to_f32(*reinterpret_cast<const uint2*>(p)); }
+  static __device__ __forceinline__ float4 ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return bf16x4_to_f32(make_uint2(v.x, v.y));
+  }
 };
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -73,62 +89,104 @@ struct TileItem {
   bool on;
 };
 
+template <typename TOut> __device__ __forceinline__ void store_quad(TOut* d, float4 v);
+template <> __device__ __forceinline__ void store_quad<float>(float* d, float4 v) { *reinterpret_cast<float4*>(d) = v; }
+template <> __device__ __forceinline__ void store_quad<__half>(__half* d, float4 v) {
+  const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+  uint2 r; r.x = *reinterpret_cast<const uint32_t*>(&a); r.y = *reinterpret_cast<const uint32_t*>(&b);
+  *reinterpret_cast<uint2*>(d) = r;
+}
+template <> __device__ __forceinline__ void store_quad<bf16_t>(bf16_t* d, float4 v) {
+  uint2 r;
+  r.x = (uint32_t)from_f32<bf16_t>(v.x).bits | ((uint32_t)from_f32<bf16_t>(v.y).bits << 16);
+  r.y = (uint32_t)from_f32<bf16_t>(v.z).bits | ((uint32_t)from_f32<bf16_t>(v.w).bits << 16);
+  *reinterpret_cast<uint2*>(d) = r;
+}
+
+enum { kStageScalar = 0, kStageVec = 1, kStageVecUnaligned = 2 };
+
+struct TileGeom {            // one cluster, all uniform
+  int first, count;          // RoIs troi[first .. first + count)
+  int y0, x0a, ngx, npos;    // window origin (x aligned down to 4), 4-pixel pieces per row, pieces in the window
+  int plane;                 // LDS slots (16 B) per quad image
+  int nq_pass;               // channel quads staged + pooled per pass
+  int mode;                  // kStage*
+};
+
 // One cluster: stage + pool every channel quad of this workgroup's channel block.
-// Register pipeline: a thread carries up to kTileUnits 16-byte row pieces per pass; unit u = q * KC + i is piece-chunk i
+// Register pipeline: a thread carries up to kUnits 16-byte row pieces per pass; unit u = q * KC + i is piece-chunk i
 // (16 consecutive pieces x 4 channels per wave-instruction) of channel quad q, so a pass stages nq_pass quads with
-// KC * nq_pass <= kTileUnits.  All loads of pass n+1 are issued before pass n is pooled and written to LDS after it.
+// KC * nq_pass <= kUnits.  Per pass:   commit(p) + store_slab(p-1) | barrier | issue(p+1) + pool(p) -> slab | barrier
+// i.e. the loads of pass p+1 are in flight (registers) while pass p is pooled, and the pooled [RoI][channel][bin] slab of
+// pass p leaves for global memory as contiguous 16-byte stores while pass p+1 is being committed.
 template <typename TIn, typename TOut, int NT>
-__device__ __forceinline__ void tile_passes(const dtc_feat_level& L, const TIn* fbase, int nc, int bins, float* win,
-                                            int plane, int nq_pass, int y0, int x0a, int ngx, int npos, bool vec,
-                                            const TileItem& it, TOut* ob) {
+__device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_feat_level& L, const TIn* fbase, int c0, int nc,
+                                            int bins, float* slab, float* win, const TileRoi* troi, const TileGeom& g,
+                                            const TileItem& it, int rl, int bin, int ablate) {
   constexpr int NW = NT / 64;
   constexpr int U = TileShape<NT>::kUnits;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, cl = (lane >> 4) & 3;
+  const int npos = g.npos, ngx = g.ngx, plane = g.plane, nq_pass = g.nq_pass;
   const int nchunk = (npos + 15) >> 4;
   const int KC = ceil_div(nchunk, NW);
   const float rinv = 1.0f / (float)ngx;
   const int nq_tot = ceil_div(nc, 4);
-  uint32_t uoff[U];     // byte offset of the unit's piece (row, 4 pixels, channel 4q + cl) from the pass base plane
+  const bool vec = g.mode != kStageScalar;
+  uint32_t uoff[U];     // byte offset of the unit's piece (row, 4 pixels, channel 4q + cl) from the pass base plane; bits 30-31:
+                        // how many pixels the piece was shifted left to stay inside its row (kStageVecUnaligned)
   int ulds[U];          // float index of (first pixel of the piece, channel cl) in the LDS image
+  // every pass is full: nq_pass divides the number of quads (caller), so nu = KC * nq_pass units carry data; the remaining
+  // register slots DUPLICATE unit 0 (same bytes to the same LDS words) -- issue / commit are branch-free straight-line code,
+  // all loads of a pass leave back to back.
+  const int nu = KC * nq_pass;
   if (vec) {
     const int sh32 = (int)L.stride_h, sc32 = (int)L.stride_c;
     int q = 0, i = 0;
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const int pos = min((wv + i * NW) * 16 + pl, npos - 1);    // lanes past the window duplicate its last piece (same bytes)
+      const bool dup = u >= nu;
+      const int pos = min((wv + (dup ? 0 : i) * NW) * 16 + pl, npos - 1);   // lanes past the window duplicate its last piece
       const int row = (int)(((float)pos + 0.5f) * rinv);         // exact: pos < 2^13, distance to an integer >= 0.5 / ngx
       const int gx = pos - row * ngx;
-      // 32-bit arithmetic throughout (vec guarantees the offsets fit): keeps the loads in SGPR-base + 32-bit-lane-offset form
-      uoff[u] = (uint32_t)((y0 + row) * sh32 + (x0a + 4 * gx) + (4 * q + cl) * sc32) * (uint32_t)sizeof(TIn);
-      ulds[u] = q * plane * 4 + ((4 * pos + (pos >> 1)) << 2) + cl;
+      const int qq = dup ? 0 : q;
+      int col = g.x0a + 4 * gx, sft = 0;
+      if (g.mode == kStageVecUnaligned) { sft = max(0, col + 3 - (L.width - 1)); col -= sft; }   // last piece of a row: stay in the row
+      uoff[u] = ((uint32_t)((g.y0 + row) * sh32 + col + (4 * qq + cl) * sc32) * (uint32_t)sizeof(TIn)) | ((uint32_t)sft << 30);
+      ulds[u] = qq * plane * 4 + ((4 * pos + (pos >> 1)) << 2) + cl;
       if (++i == KC) { i = 0; q++; }
     }
   }
+  const __amdgpu_buffer_rsrc_t srd = make_srd(fbase);
+  const uint32_t pass_bytes = (uint32_t)(L.stride_c * (int64_t)sizeof(TIn));       // per channel
   float4 v[U];
-  auto issue = [&](int cs) {      // vec only: every staged channel exists (nc % 4 == 0) and rows are 16-byte aligned
-    const int nu = KC * min(nq_pass, nq_tot - (cs >> 2));
-    // uniform base (SGPR pair) + 32-bit lane offset; uni() hides the pass offset from loop strength reduction, which would
-    // otherwise turn every unit into its own 64-bit pointer induction variable (16 VGPRs)
-    const char* base = reinterpret_cast<const char*>(fbase + (int64_t)uni(cs) * L.stride_c);
+  auto issue = [&](int cs) {      // vec only: every staged channel exists (nc % 4 == 0)
+    if (ablate & 4) return;
+    const uint32_t soff = (uint32_t)cs * pass_bytes;
+    if (g.mode == kStageVec) {
 #pragma unroll
-    for (int u = 0; u < U; u++)
-      if (u < nu) {
-        uint32_t o = uoff[u];
-        asm volatile("" : "+v"(o));       // keep the zero-extension next to the load (a hoisted one costs a second VGPR per unit)
-        v[u] = Piece4<TIn>::ld(base + o);
-      }
-  };
-  auto commit = [&](int cs) {
-    const int nu = KC * min(nq_pass, nq_tot - (cs >> 2));
+      for (int u = 0; u < U; u++) v[u] = Piece4<TIn>::ld(srd, uoff[u], soff);
+    } else {
 #pragma unroll
-    for (int u = 0; u < U; u++)
-      if (u < nu) {
-        float* d = win + ulds[u];
-        d[0] = v[u].x; d[4] = v[u].y; d[8] = v[u].z; d[12] = v[u].w;
-      }
+      for (int u = 0; u < U; u++) v[u] = Piece4<TIn>::ld(srd, uoff[u] & 0x3fffffffu, soff);
+    }
   };
-  // Rows that are not 16-byte aligned, strided columns or a channel tail (P5's 42 columns, odd maps, C % 4 != 0): no
-  // register pipeline, each piece is four clamped scalar loads written straight to LDS.  Correct for any strides.
+  auto commit = [&]() {
+    if (ablate & 8) return;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      float4 w = v[u];
+      if (g.mode == kStageVecUnaligned) {     // shifted piece: pixel k of the piece is component k + shift of the load
+        const uint32_t sft = uoff[u] >> 30;
+        w.x = sft == 0 ? w.x : sft == 1 ? w.y : sft == 2 ? w.z : w.w;
+        w.y = sft == 0 ? w.y : sft == 1 ? w.z : w.w;
+        w.z = sft == 0 ? w.z : w.w;             // components past the row end hold a copy of its last pixel: never sampled
+      }
+      float* d = win + ulds[u];
+      d[0] = w.x; d[4] = w.y; d[8] = w.z; d[12] = w.w;
+    }
+  };
+  // Strided columns, misaligned bases or a channel tail (channels_last maps, C % 4 != 0, maps narrower than 4): no register
+  // pipeline, each piece is four clamped scalar loads written straight to LDS.  Correct for any strides; not a fast path.
   auto stage_scalar = [&](int cs) {
 #pragma unroll 1
     for (int q = 0; q < nq_pass; q++) {
@@ -141,8 +199,8 @@ __device__ __forceinline__ void tile_passes(const dtc_feat_level& L, const TIn* 
         const int pos = min(t * 16 + pl, npos - 1);
         const int row = (int)(((float)pos + 0.5f) * rinv);
         const int gx = pos - row * ngx;
-        const int rem = L.width - 1 - (x0a + 4 * gx);               // >= 0: a piece starts inside the map
-        const TIn* s = base + (int64_t)(y0 + row) * L.stride_h + (int64_t)(x0a + 4 * gx) * L.stride_w;
+        const int rem = L.width - 1 - (g.x0a + 4 * gx);             // >= 0: a piece starts inside the map
+        const TIn* s = base + (int64_t)(g.y0 + row) * L.stride_h + (int64_t)(g.x0a + 4 * gx) * L.stride_w;
         float* d = win + q * plane * 4 + ((4 * pos + (pos >> 1)) << 2) + cl;
         d[0] = to_f32<TIn>(s[0]);
         d[4] = to_f32<TIn>(s[(int64_t)min(1, rem) * L.stride_w]);
@@ -151,16 +209,44 @@ __device__ __forceinline__ void tile_passes(const dtc_feat_level& L, const TIn* 
       }
     }
   };
+  // slab of the pass that was pooled last: [RoI of the cluster][4 * nq channels][bins] float32, contiguous per RoI exactly like
+  // the [R, C, PH, PW] output -> 16-byte stores (the output offset of channel cs is a multiple of 4 elements when C % 4 == 0)
+  const bool quad_ok = ((p.channels | c0) & 3) == 0;
+  auto store_slab = [&](int cs, int nq) {
+    if (ablate & 1) return;
+    const int nch = min(4 * nq, nc - cs);
+    TOut* out = reinterpret_cast<TOut*>(p.out);
+    if (quad_ok && nch == 4 * nq) {
+      const int n4 = nq * bins, total = g.count * n4;
+      const float r4 = 1.0f / (float)n4;
+      for (int idx = tid; idx < total; idx += NT) {
+        const int k = (int)(((float)idx + 0.5f) * r4);            // exact for idx < 2^13
+        const int e = idx - k * n4;
+        const float4 val = reinterpret_cast<const float4*>(slab)[idx];
+        store_quad<TOut>(out + ((size_t)troi[g.first + k].r * p.channels + c0 + cs) * bins + 4 * e, val);
+      }
+    } else {
+      const int per = nch * bins, total = g.count * per;
+      for (int idx = tid; idx < total; idx += NT) {
+        const int k = idx / per, e = idx - k * per;
+        out[((size_t)troi[g.first + k].r * p.channels + c0 + cs) * bins + e] = from_f32<TOut>(slab[k * 4 * nq * bins + e]);
+      }
+    }
+  };
 
   if (vec) issue(0);
+  int cs_prev = 0, nq_prev = 0;
 #pragma unroll 1
   for (int qs = 0; qs < nq_tot; qs += nq_pass) {
     const int cs = 4 * qs;
     const int nq_cur = min(nq_pass, nq_tot - qs);
-    if (vec) commit(cs); else stage_scalar(cs);
-    __syncthreads();
+    if (vec) commit(); else stage_scalar(cs);
+    if (nq_prev) store_slab(cs_prev, nq_prev);
+    if (!(ablate & 128)) __syncthreads();
+    if (ablate & 256) break;
     if (vec && qs + nq_pass < nq_tot) issue(cs + 4 * nq_pass);    // next pass: in flight (registers) while this one is pooled
-    if (it.on) {
+    if (it.on && !(ablate & 2)) {
+      float* so = slab + rl * (4 * nq_cur * bins) + bin;
 #pragma unroll 1
       for (int q = 0; q < nq_cur; q++) {
         // uniform quad offset, opaque to the optimiser: otherwise every tap address becomes its own induction variable
@@ -187,26 +273,27 @@ __device__ __forceinline__ void tile_passes(const dtc_feat_level& L, const TIn* 
           __builtin_amdgcn_sched_barrier(0);      // keep the two sample rows apart: 32, not 64, tap registers live
         }
         // :216  output_val /= count ; count == 4 -> x * 0.25f is the same float32
-        const int c = cs + 4 * q;                 // uniform
-        TOut* o = ob + (size_t)c * bins;
-        o[0] = from_f32<TOut>(a0 * 0.25f);
-        if (c + 1 < nc) o[bins] = from_f32<TOut>(a1 * 0.25f);
-        if (c + 2 < nc) o[2 * bins] = from_f32<TOut>(a2 * 0.25f);
-        if (c + 3 < nc) o[3 * bins] = from_f32<TOut>(a3 * 0.25f);
+        float* o = so + uni(4 * q * bins);
+        o[0] = a0 * 0.25f; o[bins] = a1 * 0.25f; o[2 * bins] = a2 * 0.25f; o[3 * bins] = a3 * 0.25f;
       }
     }
-    __syncthreads();
+    if (!(ablate & 128)) __syncthreads();
+    cs_prev = cs; nq_prev = nq_cur;
   }
+  if (nq_prev) store_slab(cs_prev, nq_prev);   // the next cluster writes the slab only behind its own first barrier
 }
 
 template <typename TIn, typename TOut, int NT>
-__global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes) {
+__global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct, int ablate) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileRoi* troi = reinterpret_cast<TileRoi*>(smem);
   TileGroup* tgrp = reinterpret_cast<TileGroup*>(smem + kTileMaxK * 32);
   int* ngp = reinterpret_cast<int*>(smem + 2 * kTileMaxK * 32);
-  float* win = reinterpret_cast<float*>(smem + kTileHdrBytes);
-  const int win_bytes = lds_bytes - kTileHdrBytes;
+  // [header][slab: K RoIs x 4 nq_cap channels x bins float32, fixed][image: nq quads x plane slots x 16 B]
+  const int slab_bytes = kgroup * p.pooled_h * p.pooled_w * 16 * nq_cap;
+  float* slab = reinterpret_cast<float*>(smem + kTileHdrBytes);
+  float* win = reinterpret_cast<float*>(smem + kTileHdrBytes + slab_bytes);
+  const int win_bytes = lds_bytes - kTileHdrBytes - slab_bytes;
   constexpr int NW = NT / 64;
   constexpr int kMaxPos = TileShape<NT>::kUnits * NW * 16;                  // 16-byte pieces the register pipeline can carry per quad
   const int tid = threadIdx.x;
@@ -240,9 +327,9 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
   }
   __syncthreads();
 
+  if (ablate & 16) return;
   // ---- B. greedy clustering along the visiting order (one lane; K <= 32 steps) ----------------------------------------
   if (tid == 0) {
-    const int esz = (int)sizeof(TIn);
     int ng = 0, k = 0;
     while (k < K) {
       const TileRoi a = troi[k];
@@ -256,18 +343,21 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
           g.kind = kGrpGather;
         } else {
           g.kind = kGrpPool;
-          long long cost = (long long)th0 * ((a.x1 - a.x0 + 1) * esz + 128);
+          // merge the next RoI of the visiting order while the union window stays a compact patch: at most merge_pct % of the
+          // pixels the members would stage one by one.  (Neighbours of the (level, band, x) order overlap about two-fold, so a
+          // patch of K windows is hardly larger than their sum -- but its rows are K times longer, i.e. whole 128-byte lines.)
+          long long sum_px = (long long)th0 * (a.x1 - a.x0 + 1);
           while (k + g.count < K && (g.count + 1) * bins <= NT) {
             const TileRoi n = troi[k + g.count];
             if (!n.valid || n.lvl != a.lvl || n.b != a.b) break;
             const int ux0 = min(g.x0, n.x0), ux1 = max(g.x1, n.x1), uy0 = min(g.y0, n.y0), uy1 = max(g.y1, n.y1);
             const int ungx = (ux1 >> 2) - (ux0 >> 2) + 1, uth = uy1 - uy0 + 1, unpos = uth * ungx;
             if (unpos > kMaxPos || (4 * unpos + (unpos >> 1) + 1) * 16 > win_bytes) break;
-            const long long ucost = (long long)uth * ((ux1 - ux0 + 1) * esz + 128);
-            const long long ncost = (long long)(n.y1 - n.y0 + 1) * ((n.x1 - n.x0 + 1) * esz + 128);
-            if (ucost > cost + ncost) break;                       // merging would fetch more lines than it saves
+            const long long n_px = (long long)(n.y1 - n.y0 + 1) * (n.x1 - n.x0 + 1);
+            const long long u_px = (long long)uth * (ux1 - ux0 + 1);
+            if (u_px * 100 > (sum_px + n_px) * merge_pct) break;
             g.x0 = ux0; g.x1 = ux1; g.y0 = uy0; g.y1 = uy1; g.count++;
-            cost = ucost;
+            sum_px += n_px;
           }
         }
       }
@@ -278,6 +368,7 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
   }
   __syncthreads();
 
+  if (ablate & 32) return;
   // ---- C. clusters ----------------------------------------------------------------------------------------------------
   const int ngroups = uni(*ngp);
   for (int gi = 0; gi < ngroups; gi++) {
@@ -317,22 +408,34 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
     }
     // cluster geometry (uniform)
     const int gx0 = uni(tgrp[gi].x0), gx1 = uni(tgrp[gi].x1), gy0 = uni(tgrp[gi].y0), gy1 = uni(tgrp[gi].y1);
-    const int x0a = gx0 & ~3;
-    const int ngx = (gx1 >> 2) - (gx0 >> 2) + 1;
-    const int tw = 4 * ngx, th = gy1 - gy0 + 1, npos = th * ngx;
-    const int plane = 4 * npos + (npos >> 1) + 1;           // slots per quad image
-    const bool vec = L.stride_w == 1 && ((L.width | L.stride_h | L.stride_c | L.stride_n | nc | c0) & 3) == 0 &&
-                     (reinterpret_cast<uintptr_t>(L.data) & (4 * sizeof(TIn) - 1)) == 0 && L.stride_h > 0 && L.stride_c > 0 &&
-                     L.stride_h * L.height + L.stride_c * 4 * TileShape<NT>::kUnits < (1ll << 28);     // lane offsets fit 32 bits
-    const int KC = ceil_div((npos + 15) >> 4, NW);
+    TileGeom g;
+    g.first = first; g.count = count;
+    g.y0 = gy0; g.x0a = gx0 & ~3;
+    g.ngx = (gx1 >> 2) - (gx0 >> 2) + 1;
+    const int tw = 4 * g.ngx, th = gy1 - gy0 + 1;
+    g.npos = th * g.ngx;
+    g.plane = 4 * g.npos + (g.npos >> 1) + 1;           // slots per quad image
+    // staging mode: 16-byte aligned rows -> plain 16-byte pieces; 4-byte aligned rows (width % 4 != 0) -> unaligned pieces,
+    // the last one of a row shifted left; anything else (strided columns, channel tails) -> scalar loads
+    const int esz = (int)sizeof(TIn);
+    const bool lin = L.stride_w == 1 && ((nc | c0) & 3) == 0 && L.stride_h > 0 && L.stride_c > 0 &&
+                     L.stride_h * L.height + L.stride_c * 4 * TileShape<NT>::kUnits < (1ll << 26);     // lane offsets fit 30 bits
+    const bool al16 = ((L.width | L.stride_h | L.stride_c | L.stride_n) & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(L.data) & (4 * sizeof(TIn) - 1)) == 0;
+    const bool al4 = L.width >= 4 && (((L.width | L.stride_h | L.stride_c | L.stride_n) * esz) & 3) == 0 &&
+                     (reinterpret_cast<uintptr_t>(L.data) & 3) == 0;
+    g.mode = !lin ? kStageScalar : al16 ? kStageVec : al4 ? kStageVecUnaligned : kStageScalar;
+    const int KC = ceil_div((g.npos + 15) >> 4, NW);
+    g.nq_pass = max(1, min(min(win_bytes / (g.plane * 16), TileShape<NT>::kUnits / KC), min(ceil_div(nc, 4), nq_cap)));
+    while (ceil_div(nc, 4) % g.nq_pass) g.nq_pass--;        // every pass full: no partial-pass code in the staging pipeline
     // ---- the lane's item -------------------------------------------------------------------------------------------
     const int n_it = count * bins;
     TileItem it;
     it.on = tid < n_it;
     const int itx = it.on ? tid : 0;
-    const int kk = first + itx / bins, bin = itx % bins;
+    const int rl = itx / bins, bin = itx - rl * bins;
     const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
-    const RoiHead hd = load_roi_head(p, grp * K + kk);
+    const RoiHead hd = load_roi_head(p, grp * K + first + rl);
     int ylo[2], yhi[2], xlo[2], xhi[2];      // window-relative: rows premultiplied by the window width
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -340,7 +443,7 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
       const AxisEntry ex = make_axis(hd.sw, hd.bin_w, pw, i, 2, L.width);
       it.yl[i] = ey.l; it.yh[i] = ey.h; it.xl[i] = ex.l; it.xh[i] = ex.h;
       ylo[i] = (ey.lo - gy0) * tw; yhi[i] = (ey.hi - gy0) * tw;
-      xlo[i] = ex.lo - x0a; xhi[i] = ex.hi - x0a;
+      xlo[i] = ex.lo - g.x0a; xhi[i] = ex.hi - g.x0a;
     }
 #pragma unroll
     for (int iy = 0; iy < 2; iy++)
@@ -351,9 +454,8 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
         asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));   // one finished VGPR per tap: do not re-derive in the loop
         it.a[iy][ix][0] = t0; it.a[iy][ix][1] = t1; it.a[iy][ix][2] = t2; it.a[iy][ix][3] = t3;
       }
-    TOut* ob = reinterpret_cast<TOut*>(p.out) + ((size_t)hd.r * p.channels + c0) * bins + bin;
-    const int nq_pass = max(1, min(min(win_bytes / (plane * 16), TileShape<NT>::kUnits / KC), ceil_div(nc, 4)));
-    tile_passes<TIn, TOut, NT>(L, fbase, nc, bins, win, plane, nq_pass, gy0, x0a, ngx, npos, vec, it, ob);
+    if (ablate & 64) { if (it.a[0][0][0] == 0x7fffffff && it.yl[1] == 3.f) slab[tid] = it.xh[0] + it.a[1][1][3]; continue; }
+    tile_passes<TIn, TOut, NT>(p, L, fbase, c0, nc, bins, slab, win, troi, g, it, rl, bin, ablate);
   }
 }
 
@@ -363,6 +465,9 @@ struct TileConfig {
   int lds_kb = 0;      // LDS per workgroup (0: TileShape<NT>::kLdsKB)
   int k = 0;           // RoIs per workgroup (0: threads / bins)
   int ch_block = 0;    // channels per workgroup (0: chosen per launch)
+  int merge_pct = 150; // a cluster may stage at most this % of the pixels its members would stage separately
+  int nq_cap = 0;      // channel quads per pass, upper bound (0: 2) -- sizes the LDS output slab
+  int ablate = 0;      // development: skip phases (timing ablation only -- results are WRONG when set)
 };
 static const TileConfig& tile_config() {   // development knobs, resolved ONCE (thread-safe static initialisation)
   static const TileConfig cfg = [] {
@@ -370,6 +475,9 @@ static const TileConfig& tile_config() {   // development knobs, resolved ONCE (
     if (const char* e = getenv("DTC_RA_TILE_NT")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) c.nt = v; }
     if (const char* e = getenv("DTC_RA_TILE_LDS_KB")) { const int v = atoi(e); if (v >= 8 && v <= 160) c.lds_kb = v; }
     if (const char* e = getenv("DTC_RA_TILE_K")) { const int v = atoi(e); if (v >= 1 && v <= kTileMaxK) c.k = v; }
+    if (const char* e = getenv("DTC_RA_TILE_ABLATE")) c.ablate = atoi(e);
+    if (const char* e = getenv("DTC_RA_TILE_MERGE")) { const int v = atoi(e); if (v >= 100 && v <= 100000) c.merge_pct = v; }
+    if (const char* e = getenv("DTC_RA_TILE_NQCAP")) { const int v = atoi(e); if (v >= 1 && v <= 8) c.nq_cap = v; }
     if (const char* e = getenv("DTC_RA_TILE_CHBLOCK")) { const int v = atoi(e); if (v >= 4 && (v & 3) == 0) c.ch_block = v; }
     return c;
   }();
@@ -392,6 +500,8 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   if (attr_rc != hipSuccess) return DTC_ELAUNCH;
+  const int nq_cap = cfg.nq_cap ? cfg.nq_cap : 2;
+  if (kTileHdrBytes + K * bins * 16 * nq_cap + 20 * 1024 > lds_b) return DTC_EUNSUPPORTED;
   const int ngrp = ceil_div(p.n_rois, K);
   // channels per workgroup: the per-cluster setup (geometry, item registers) is paid once per block; keep >= ~4 workgroups per CU
   int cb = cfg.ch_block ? cfg.ch_block : 128;
@@ -399,7 +509,7 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   p.ch_block = cb;
   p.xcd_remap = 1;
   const int nct = ceil_div(p.channels, p.ch_block);
-  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b);
+  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, cfg.ablate);
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }
