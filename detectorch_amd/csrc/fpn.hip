@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(Fpn
   if (p.roi_order) {
     // visiting order for RoIAlign.  Purely a performance hint; any permutation is correct.
     __syncthreads();
-    const int np2o = next_pow2(p.top_n);
+    const int np2o = max(4, next_pow2(p.top_n));     // the counting rank below reads the key table four entries at a time
     for (int r = tid; r < np2o; r += kFpnThreads) {
       uint64_t k = kPadKey;
       if (r < p.top_n) {
@@ -255,11 +255,14 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
   p.in_boxes = in_boxes; p.in_scores = in_scores; p.in_counts = in_counts; p.L_in = n_in_levels; p.P = in_stride;
   p.top_n = post_nms_top_n; p.k_min = k_min; p.k_max = k_max; p.inputs_sorted = inputs_sorted; p.rois5 = rois5; p.roi_scores = roi_scores;
   p.roi_levels = roi_levels; p.n_out = n_out; p.rois_by_level = rois_by_level; p.level_counts = level_counts;
-  p.band_log2 = getenv("DTC_FPN_BAND_LOG2") ? atoi(getenv("DTC_FPN_BAND_LOG2")) : 5;
+  // visiting-order band height (log2 feature rows): 16 rows suits the cluster-stationary RoIAlign kernel (clusters of ~5
+  // neighbours stay ~28 rows x 32 pixels; measured 8 rows 0.48, 16 rows 0.41, 32 rows 0.43 ms per 8000-RoI box-head launch)
+  static const int band_log2 = [] { const char* e = getenv("DTC_FPN_BAND_LOG2"); const int v = e ? atoi(e) : 4; return v < 0 || v > 8 ? 4 : v; }();
+  p.band_log2 = band_log2;
   p.idx_restore = idx_restore; p.roi_order = roi_order; p.roi_desc = roi_order ? roi_desc : nullptr;
   size_t smem = in_scores ? (size_t)dtc::next_pow2((int)n_max) * sizeof(uint64_t) : 16;
   if (in_scores && inputs_sorted) smem = (size_t)post_nms_top_n * sizeof(uint64_t) + (size_t)n_max * sizeof(float) + 16;
-  if (roi_order) { const size_t so = (size_t)dtc::next_pow2(post_nms_top_n) * sizeof(uint64_t) * 2; if (so > smem) smem = so; }
+  if (roi_order) { const size_t so = (size_t)(dtc::next_pow2(post_nms_top_n) < 4 ? 4 : dtc::next_pow2(post_nms_top_n)) * sizeof(uint64_t) * 2; if (so > smem) smem = so; }
   if (post_nms_top_n > 16384) return DTC_EUNSUPPORTED;
   if (smem > 64 * 1024) {
     static bool raised = false;

@@ -122,7 +122,7 @@ struct TileGeom {            // one cluster, all uniform
 template <typename TIn, typename TOut, int NT>
 __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_feat_level& L, const TIn* fbase, int c0, int nc,
                                             int bins, float* slab, float* win, const TileRoi* troi, const TileGeom& g,
-                                            const TileItem& it, int rl, int bin, int ablate) {
+                                            const TileItem& it, int rl, int bin) {
   constexpr int NW = NT / 64;
   constexpr int U = TileShape<NT>::kUnits;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, cl = (lane >> 4) & 3;
@@ -160,7 +160,6 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
   const uint32_t pass_bytes = (uint32_t)(L.stride_c * (int64_t)sizeof(TIn));       // per channel
   float4 v[U];
   auto issue = [&](int cs) {      // vec only: every staged channel exists (nc % 4 == 0)
-    if (ablate & 4) return;
     const uint32_t soff = (uint32_t)cs * pass_bytes;
     if (g.mode == kStageVec) {
 #pragma unroll
@@ -171,7 +170,6 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
     }
   };
   auto commit = [&]() {
-    if (ablate & 8) return;
 #pragma unroll
     for (int u = 0; u < U; u++) {
       float4 w = v[u];
@@ -213,7 +211,6 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
   // the [R, C, PH, PW] output -> 16-byte stores (the output offset of channel cs is a multiple of 4 elements when C % 4 == 0)
   const bool quad_ok = ((p.channels | c0) & 3) == 0;
   auto store_slab = [&](int cs, int nq) {
-    if (ablate & 1) return;
     const int nch = min(4 * nq, nc - cs);
     TOut* out = reinterpret_cast<TOut*>(p.out);
     if (quad_ok && nch == 4 * nq) {
@@ -242,10 +239,9 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
     const int nq_cur = min(nq_pass, nq_tot - qs);
     if (vec) commit(); else stage_scalar(cs);
     if (nq_prev) store_slab(cs_prev, nq_prev);
-    if (!(ablate & 128)) __syncthreads();
-    if (ablate & 256) break;
+    __syncthreads();
     if (vec && qs + nq_pass < nq_tot) issue(cs + 4 * nq_pass);    // next pass: in flight (registers) while this one is pooled
-    if (it.on && !(ablate & 2)) {
+    if (it.on) {
       float* so = slab + rl * (4 * nq_cur * bins) + bin;
 #pragma unroll 1
       for (int q = 0; q < nq_cur; q++) {
@@ -277,14 +273,14 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
         o[0] = a0 * 0.25f; o[bins] = a1 * 0.25f; o[2 * bins] = a2 * 0.25f; o[3 * bins] = a3 * 0.25f;
       }
     }
-    if (!(ablate & 128)) __syncthreads();
+    __syncthreads();
     cs_prev = cs; nq_prev = nq_cur;
   }
   if (nq_prev) store_slab(cs_prev, nq_prev);   // the next cluster writes the slab only behind its own first barrier
 }
 
 template <typename TIn, typename TOut, int NT>
-__global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct, int ablate) {
+__global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileRoi* troi = reinterpret_cast<TileRoi*>(smem);
   TileGroup* tgrp = reinterpret_cast<TileGroup*>(smem + kTileMaxK * 32);
@@ -327,7 +323,6 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
   }
   __syncthreads();
 
-  if (ablate & 16) return;
   // ---- B. greedy clustering along the visiting order (one lane; K <= 32 steps) ----------------------------------------
   if (tid == 0) {
     int ng = 0, k = 0;
@@ -368,7 +363,6 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
   }
   __syncthreads();
 
-  if (ablate & 32) return;
   // ---- C. clusters ----------------------------------------------------------------------------------------------------
   const int ngroups = uni(*ngp);
   for (int gi = 0; gi < ngroups; gi++) {
@@ -454,8 +448,7 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
         asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));   // one finished VGPR per tap: do not re-derive in the loop
         it.a[iy][ix][0] = t0; it.a[iy][ix][1] = t1; it.a[iy][ix][2] = t2; it.a[iy][ix][3] = t3;
       }
-    if (ablate & 64) { if (it.a[0][0][0] == 0x7fffffff && it.yl[1] == 3.f) slab[tid] = it.xh[0] + it.a[1][1][3]; continue; }
-    tile_passes<TIn, TOut, NT>(p, L, fbase, c0, nc, bins, slab, win, troi, g, it, rl, bin, ablate);
+    tile_passes<TIn, TOut, NT>(p, L, fbase, c0, nc, bins, slab, win, troi, g, it, rl, bin);
   }
 }
 
@@ -465,9 +458,8 @@ struct TileConfig {
   int lds_kb = 0;      // LDS per workgroup (0: TileShape<NT>::kLdsKB)
   int k = 0;           // RoIs per workgroup (0: threads / bins)
   int ch_block = 0;    // channels per workgroup (0: chosen per launch)
-  int merge_pct = 150; // a cluster may stage at most this % of the pixels its members would stage separately
-  int nq_cap = 0;      // channel quads per pass, upper bound (0: 2) -- sizes the LDS output slab
-  int ablate = 0;      // development: skip phases (timing ablation only -- results are WRONG when set)
+  int merge_pct = 250; // a cluster may stage at most this % of the pixels its members would stage separately
+  int nq_cap = 0;      // channel quads per pass, upper bound (0: 4) -- sizes the LDS output slab
 };
 static const TileConfig& tile_config() {   // development knobs, resolved ONCE (thread-safe static initialisation)
   static const TileConfig cfg = [] {
@@ -475,7 +467,6 @@ static const TileConfig& tile_config() {   // development knobs, resolved ONCE (
     if (const char* e = getenv("DTC_RA_TILE_NT")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) c.nt = v; }
     if (const char* e = getenv("DTC_RA_TILE_LDS_KB")) { const int v = atoi(e); if (v >= 8 && v <= 160) c.lds_kb = v; }
     if (const char* e = getenv("DTC_RA_TILE_K")) { const int v = atoi(e); if (v >= 1 && v <= kTileMaxK) c.k = v; }
-    if (const char* e = getenv("DTC_RA_TILE_ABLATE")) c.ablate = atoi(e);
     if (const char* e = getenv("DTC_RA_TILE_MERGE")) { const int v = atoi(e); if (v >= 100 && v <= 100000) c.merge_pct = v; }
     if (const char* e = getenv("DTC_RA_TILE_NQCAP")) { const int v = atoi(e); if (v >= 1 && v <= 8) c.nq_cap = v; }
     if (const char* e = getenv("DTC_RA_TILE_CHBLOCK")) { const int v = atoi(e); if (v >= 4 && (v & 3) == 0) c.ch_block = v; }
@@ -500,16 +491,16 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   if (attr_rc != hipSuccess) return DTC_ELAUNCH;
-  const int nq_cap = cfg.nq_cap ? cfg.nq_cap : 2;
+  const int nq_cap = cfg.nq_cap ? cfg.nq_cap : 4;
   if (kTileHdrBytes + K * bins * 16 * nq_cap + 20 * 1024 > lds_b) return DTC_EUNSUPPORTED;
   const int ngrp = ceil_div(p.n_rois, K);
   // channels per workgroup: the per-cluster setup (geometry, item registers) is paid once per block; keep >= ~4 workgroups per CU
-  int cb = cfg.ch_block ? cfg.ch_block : 128;
+  int cb = cfg.ch_block ? cfg.ch_block : 64;     // measured on MI355X (8000 RoIs x 256 ch): 32 -> 0.48, 64 -> 0.41, 128 -> 0.42 ms
   while (cb > 32 && (long long)ngrp * ceil_div(p.channels, cb) < 2048) cb >>= 1;
   p.ch_block = cb;
   p.xcd_remap = 1;
   const int nct = ceil_div(p.channels, p.ch_block);
-  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, cfg.ablate);
+  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct);
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }

@@ -77,6 +77,35 @@ def test_collect_distribute_batched_vs_oracle(hip, oracle):
         assert np.array_equal(res["rois_by_level"][b, :n].cpu().numpy(), np.concatenate(outs) if n else np.zeros((0, 4)))
 
 
+@pytest.mark.parametrize("T", [1, 2, 3, 5, 7, 64, 1000])
+def test_visiting_order_is_a_permutation_for_tiny_top_n(hip, T):
+    """roi_order / roi_desc (the RoIAlign visiting order) for very small top-N: round-1 read the rank table four entries at
+    a time but initialised only next_pow2(T) of them (T = 1, 2 broke; utils.multilevel_rois hits this on every image with
+    1-2 detections).  Any T: roi_order is a permutation of the image's rows, roi_desc repeats rois5 / level / row."""
+    B, P = 2, max(T, 4)
+    rs = synth.rng(4, 60 + T)
+    boxes = np.stack([synth.make_rois(rs, P) for _ in range(B)])[:, None]                   # [B,1,P,4]
+    counts = np.full((B, 1), T, np.int32)
+    res = hip.fpn_collect_distribute(cu(boxes), None, cu(counts), T, 2, 5)
+    order = res["roi_order"].cpu().numpy()
+    desc = res["roi_desc"].cpu().numpy()
+    rois5 = res["rois5"].cpu().numpy()
+    lv = res["roi_levels"].cpu().numpy()
+    for b in range(B):
+        assert sorted(order[b].tolist()) == list(range(b * T, (b + 1) * T))
+        for i in range(T):
+            r = order[b, i] - b * T
+            assert np.array_equal(desc[b, i, :5], rois5[b, r]) and desc[b, i, 5] == lv[b, r] and desc[b, i, 6] == order[b, i]
+    # and RoIAlign driven by those descriptors equals RoIAlign in plain order
+    feats = [cu(synth.make_features(rs, (B, 8, h, w))) for (h, w) in synth.fpn_level_shapes()[:4]]
+    ref = hip.roi_align_forward(feats, synth.FPN_ROI_SCALES, res["rois5"].reshape(-1, 5), 7, 7, 2, roi_levels=res["roi_levels"].reshape(-1))
+    out = torch.full((B * T, 8, 7, 7), -1.0, device="cuda")
+    lvs, ch, dt = hip.make_levels(feats, synth.FPN_ROI_SCALES)
+    assert hip.lib().dtc_roi_align_forward_packed(lvs, 4, ch, 0, res["roi_desc"].data_ptr(), B * T, 7, 7, 2, out.data_ptr(), 0,
+                                                  hip.stream_ptr()) == 0
+    assert torch.equal(out, ref)
+
+
 # ---------------------------------------------------------------- A8 ------------------------------------------------
 def test_postprocess_golden_module(hip):
     from detectorch_amd.utils import result_utils
