@@ -1,21 +1,35 @@
 #!/usr/bin/env python3
 """Contract benchmark: images/sec of the Mask R-CNN R-50-FPN region-proposal hot path on 1333x800 COCO-shaped synthetic
-input (BASELINE.json metric, config[2]: "Mask R-CNN R-50-FPN, 1 MI355X, 4-level RoIAlign + 14x14 mask head").
+input (BASELINE.json metric; default workload = configs[2]: "Mask R-CNN R-50-FPN, 1 MI355X, 4-level RoIAlign + 14x14 mask
+head").
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg5|cfg2]
+
+With N > 1 and no launcher environment the script re-executes itself under `python -m torch.distributed.run` with N ranks
+(one per GPU, RCCL); launched by the driver's own torchrun line it just uses the environment it is given.  `n_gpus` in the
+output is the size of the process group that actually ran.
 
 One "step" = one pass of the whole hot path (detectorch_amd.pipeline.FpnRegionPath: GenerateProposals x5 levels, NMS,
 collect/distribute, 4-level RoIAlign 7x7, detection post-processing, mask-branch RoIAlign 14x14, mask resize/binarise)
-over one batch of --batch images per GPU, inputs already resident in HBM.  The ResNet/FPN convs and the box/mask-head
-GEMMs are not part of the path (they stay on MIOpen/hipBLASLt); their outputs are synthetic tensors of the right shape.
-Images shard across ranks with no data-path collective ("weak" scaling: fixed images per GPU); the only exchange is one
-RCCL all_gather of the padded detections per step (detectorch_amd.dist), which IS inside the timed region.
+over one batch of --batch images per GPU, inputs already resident in HBM; consecutive steps alternate between TWO bound
+input sets (different seeds), so no step re-reads what the previous one left in the caches.  The ResNet/FPN convs and the
+box/mask-head GEMMs are not part of the path (they stay on MIOpen/hipBLASLt); their outputs are synthetic tensors of the
+right shape.  Images shard across ranks with no data-path collective ("weak" scaling: fixed images per GPU); the only
+exchange is one RCCL all_gather of the padded detections per step (detectorch_amd.dist), INSIDE the timed region.
 
-Prints ONE JSON line on rank 0 (fields: see the task contract + `roofline` + `cpu_baseline`).
+Workloads (BASELINE.json configs):
+  cfg3 (default)  configs[2]  Mask R-CNN R-50-FPN, 1000 rois / image, fp32 NCHW features
+  cfg5            configs[4]  same path, 2000 proposals / image (collect top-N 2000) and fp16 feature maps / pooled features
+  cfg2            configs[1]  Faster R-CNN R-50-C4: 63 000 anchors -> 6000 -> NMS -> 1000 proposals, RoIAlign 7x7
+                              (adaptive sampling) on res4 [B,1024,50,84], per-class NMS (detectorch_amd.pipeline.C4RegionPath)
+
+Prints ONE JSON line on rank 0 (fields: the task contract + `roofline` + `cpu_baseline` + `consistency`).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,25 +45,40 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=["cfg3", "cfg5", "cfg2"], default="cfg3")
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (BASELINE cfg4: 8 images/GPU)")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying the hipGraph")
     ap.add_argument("--channels-last", action="store_true", help="NHWC feature maps (same logical shape)")
-    ap.add_argument("--fp16", action="store_true", help="fp16 feature maps / pooled features (BASELINE cfg5 flavour)")
+    ap.add_argument("--fp16", action="store_true", help="fp16 feature maps / pooled features (cfg5 sets this itself)")
+    ap.add_argument("--c4-pooled", type=int, default=7, help="cfg2: pooled size (7 as BASELINE names it; 14 = the reference's C4 default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=8, help="images of the same workload timed on the CPU oracle")
+    ap.add_argument("--cpu-images", type=int, default=8, help="images of the same workload run on the CPU oracle (timed + compared with the GPU)")
     ap.add_argument("--kernel-iters", type=int, default=20)
-    ap.add_argument("--split", type=int, default=1, help="sub-batches run on separate HIP streams inside one hipGraph")
+    ap.add_argument("--sustain-seconds", type=float, default=1.0, help="extra untimed-by-contract run of at least this long, reported under `consistency`")
+    ap.add_argument("--split", type=int, default=1, help="sub-batches run on separate HIP streams inside one hipGraph (cfg3/cfg5)")
     return ap.parse_args()
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, RCCL over xGMI)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+# ---- CPU baseline (+ the parity check of the benchmarked configuration) -------------------------------------------------
 def _cpu_all_cores(jobs, budget_s=60.0):
     """All-cores figure: P = min(host cores, 32) worker processes (oracle/cpu_worker.py, one image each, the
     n distinct images reused round-robin), inputs handed over as memory-mapped .npy files, a file barrier, wall clock from
     the common start to the last finish.  Returns images/sec over all workers."""
     import shutil
-    import subprocess
     import tempfile
     n = len(jobs)
     procs = max(1, min(os.cpu_count() or 1, 32))
@@ -86,7 +115,7 @@ def _cpu_all_cores(jobs, budget_s=60.0):
         wall = max(e for _, e in spans) - min(s for s, _ in spans)
         return {"value": round(procs / wall, 4), "unit": "images/sec", "processes": procs,
                 "note": "%d worker processes x 1 image each (the %d sample images round-robin), common start, wall clock to the "
-                        "last finish; single-threaded oracle per process" % (procs, n)}
+                        "last finish; single-threaded oracle port per process" % (procs, n)}
     finally:
         for p in ws:
             if p.poll() is None:
@@ -94,142 +123,241 @@ def _cpu_all_cores(jobs, budget_s=60.0):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def cpu_baseline(inputs, path, n_images):
-    """Time the oracle (a plain-C port of the reference's CPU path, oracle/oracle.c) on the first n_images images of the
-    same workload, single thread -- the reference itself is single-threaded (OpenMP pragma commented out at
-    lib/cppcuda/roi_align_cpu.cpp:136-137; Cython loops are serial).  Also reported: the same images run
-    image-parallel, one process per image on all host cores.  The oracle is the CHECKER, timed here as a reported baseline
-    only."""
+def cpu_baseline(workload, inputs, path, n_images, c4_pooled):
+    """Run the CPU checker on the first n_images images of the SAME inputs the timed GPU steps used, (1) time it -- single
+    thread: the reference is single-threaded (OpenMP pragma commented out at lib/cppcuda/roi_align_cpu.cpp:136-137; Cython
+    loops are serial) -- and (2) compare every intermediate with what the GPU path produced for those images
+    (`parity_checked`; a mismatch fails the run).  RoIAlign, ~90 % of the CPU time, runs the reference's own
+    roi_align_cpu_loop.cpp compiled unmodified (oracle/_ref/libref_roialign.so, built by `make -C oracle ref`) when that
+    library has travelled to this host (`kind: "reference"`); the remaining stages, and everything when it has not
+    (`kind: "port"`), run oracle/oracle.c, the plain-C restatement pinned to the reference in the CPU test-suite."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import chain  # noqa: E402  (test infrastructure: allowed in the cpu_baseline leg only)
-    rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, sf, im_size = inputs
+    import ref_harness  # noqa: E402
+    ref_ra = None
+    if os.path.exists(os.path.join(ref_harness.REF_BUILD, "libref_roialign.so")):
+        try:
+            ref_harness.load_ref_roialign()
+            ref_ra = ref_harness.ref_roi_align
+        except OSError:
+            ref_ra = None
     n = min(n_images, path.B)
     host = lambda t: t.float().cpu().numpy()
-    jobs = [([host(c[b]) for c in rpn_cls], [host(d[b]) for d in rpn_bbox], [host(f[b:b + 1]) for f in feats],
-             host(cls_score[b]), host(bbox_pred[b]), host(masks[b * path.max_out:(b + 1) * path.max_out]),
-             float(sf[b]), host(im_size[b]), path.pad_h, path.pad_w) for b in range(n)]
     T = {}
-    t0 = time.perf_counter()
-    for job in jobs:
-        chain.fpn_hot_path(*job, timings=T)
-    dt = time.perf_counter() - t0
+    refs = []
+    if workload == "cfg2":
+        rpn_cls, rpn_bbox, feat, cls_score, bbox_pred, sf, im_size = inputs
+        t0 = time.perf_counter()
+        for b in range(n):
+            refs.append(chain.c4_hot_path(host(rpn_cls[b]), host(rpn_bbox[b]), host(feat[b:b + 1]), host(cls_score[b]), host(bbox_pred[b]),
+                                          float(sf[b]), host(im_size[b]), path.im_h, path.im_w, pooled=c4_pooled, timings=T, roi_align=ref_ra))
+        dt = time.perf_counter() - t0
+        for b in range(n):
+            chain.compare_c4_with_gpu(path, b, refs[b])
+        jobs = None
+    else:
+        rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, sf, im_size = inputs
+        jobs = [([host(c[b]) for c in rpn_cls], [host(d[b]) for d in rpn_bbox], [host(f[b:b + 1]) for f in feats],
+                 host(cls_score[b]), host(bbox_pred[b]), host(masks[b * path.max_out:(b + 1) * path.max_out]),
+                 float(sf[b]), host(im_size[b]), path.pad_h, path.pad_w) for b in range(n)]
+        t0 = time.perf_counter()
+        for job in jobs:
+            refs.append(chain.fpn_hot_path(*job, top_n=path.top_n, timings=T, roi_align=ref_ra))
+        dt = time.perf_counter() - t0
+        if path.feat_dtype == torch.float32:
+            for b in range(n):
+                chain.compare_with_gpu(path, b, refs[b], int(im_size[b, 0]), int(im_size[b, 1]))
+        else:   # fp16 pooled features: indices / boxes / detections exact, features to fp16 rounding (rel 1e-3)
+            for b in range(n):
+                r, k = refs[b], int(path.n_rois[b])
+                assert k == r["rois"].shape[0] and np.array_equal(path.rois5[b, :k, 1:].cpu().numpy(), r["rois"])
+                assert np.array_equal(path.roi_levels[b, :k].cpu().numpy(), r["roi_levels"])
+                got = path.box_feats[b * path.top_n:b * path.top_n + k].float().cpu().numpy()
+                assert np.allclose(got, r["box_feats"], rtol=1e-3, atol=1e-3)
+                D = min(int(path.det_count[b]), path.max_out)
+                assert np.array_equal(path.dets[b, :D].cpu().numpy(), r["dets"][:D])
     conv = sum(T.values())
-    out = {"value": round(n / conv, 4), "unit": "images/sec", "cores": 1, "kind": "port",
-           "sample": "%d images of the same synthetic cfg3 workload (R=1000, C=256), oracle/oracle.c via ctypes, "
-                     "%.1f s CPU; per-stage s/img: %s" % (n, dt, {k: round(v / n, 4) for k, v in T.items()}),
-           "host_cpus": os.cpu_count()}
-    try:   # informational; the single-core figure above is the contract
-        out["all_cores"] = _cpu_all_cores(jobs)
-    except Exception as e:
-        out["all_cores"] = {"error": repr(e)}
+    out = {"value": round(n / conv, 4), "unit": "images/sec", "cores": 1, "kind": "reference" if ref_ra else "port",
+           "sample": "%d images of the same synthetic %s inputs the GPU steps ran, one thread, %.1f s CPU; RoIAlign = %s; "
+                     "other stages = oracle/oracle.c (plain-C port); per-stage s/img: %s"
+                     % (n, workload, dt, "the reference's roi_align_cpu_loop.cpp compiled unmodified (oracle/_ref)" if ref_ra
+                        else "oracle/oracle.c (plain-C port)", {k: round(v / n, 4) for k, v in T.items()}),
+           "host_cpus": os.cpu_count(),
+           "parity_checked": {"images": n, "ok": True,
+                              "what": "every intermediate of the benchmarked configuration (proposals, NMS survivors, rois, "
+                                      "level ids, pooled features, detections%s) == CPU checker, bit-exact%s"
+                                      % (", mask-branch features, binarised crops" if workload != "cfg2" else "",
+                                         "" if workload != "cfg5" else " (fp16 pooled features: rel 1e-3)")}}
+    if jobs is not None:
+        try:   # informational; the single-core figure above is the contract
+            out["all_cores"] = _cpu_all_cores(jobs)
+        except Exception as e:
+            out["all_cores"] = {"error": repr(e)}
     return out
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if world_env != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world_env))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    world = 1
+    if world_env > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world_env, device_id=dev)
+        world = dist.get_world_size()
+        assert world == a.gpus, (world, a.gpus)
 
     from detectorch_amd import hip
-    from detectorch_amd.pipeline import FpnRegionPath, OverlappedRegionPath, synthetic_batch
+    from detectorch_amd.pipeline import C4RegionPath, FpnRegionPath, OverlappedRegionPath, synthetic_batch, synthetic_c4_batch
     hip.lib()   # fails loudly if the native library is missing
-    fdt = torch.float16 if a.fp16 else torch.float32
-    if a.split > 1 and a.batch % a.split == 0:
-        path = OverlappedRegionPath(a.batch, dev, n_split=a.split, feat_dtype=fdt)
-    else:
-        path = FpnRegionPath(a.batch, dev, feat_dtype=fdt)
-    inputs = synthetic_batch(a.batch, dev, seed=3000 + rank, feat_dtype=fdt, channels_last=a.channels_last)
-    path.bind(*inputs)
+    wl = a.workload
+    fp16 = a.fp16 or wl == "cfg5"
+    fdt = torch.float16 if fp16 else torch.float32
+    top_n = 2000 if wl == "cfg5" else 1000
+    NSETS = 2
+    paths, inputs = [], []
+    for s in range(NSETS):
+        seed = {"cfg3": 3000, "cfg5": 5000, "cfg2": 2000}[wl] + 500 * s + rank
+        if wl == "cfg2":
+            p = C4RegionPath(a.batch, dev, pooled=a.c4_pooled, feat_dtype=fdt)
+            inp = synthetic_c4_batch(a.batch, dev, seed=seed, feat_dtype=fdt)
+        else:
+            kw = dict(feat_dtype=fdt, collect_top_n=top_n)
+            if a.split > 1 and a.batch % a.split == 0:
+                p = OverlappedRegionPath(a.batch, dev, n_split=a.split, **kw)
+            else:
+                p = FpnRegionPath(a.batch, dev, **kw)
+            inp = synthetic_batch(a.batch, dev, seed=seed, top_n=top_n, feat_dtype=fdt, channels_last=a.channels_last)
+        p.bind(*inp)
+        paths.append(p)
+        inputs.append(inp)
     gather = None
     if world > 1:
         from detectorch_amd.dist import DetectionGatherer
-        gather = DetectionGatherer(path.B, path.max_out, dev, world)
+        gather = DetectionGatherer(paths[0].B, paths[0].max_out, dev, world)
+
+    counter = [0]
 
     def one_step():
-        path.step(use_graph=not a.eager)
+        p = paths[counter[0] % NSETS]
+        counter[0] += 1
+        p.step(use_graph=not a.eager)
         if gather is not None:
-            gather.all_gather_async(path.dets, path.det_count)      # one packed collective per step, overlapped with the next
+            gather.all_gather_async(p.dets, p.det_count)      # one packed collective per step, overlapped with the next
 
-    for _ in range(a.warmup):
+    def timed(n_steps):
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            one_step()
+        if gather is not None:
+            gather.finish()                  # the last steps' collectives complete INSIDE the timed region
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    for _ in range(max(a.warmup, NSETS)):    # at least one eager + capture pass per input set
         one_step()
     if gather is not None:
         gather.finish()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_step()
-    if gather is not None:
-        gather.finish()                  # the last steps' collectives complete INSIDE the timed region
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    counter[0] = 0
+    dt = timed(a.steps)                      # the contract: exactly K steps, barrier + synchronize on both sides, max over ranks
+    # a longer run of the same loop (>= --sustain-seconds): the contract region is only K steps long
+    n_sus = int(max(a.steps, np.ceil(a.sustain_seconds / max(dt / a.steps, 1e-6)))) if a.sustain_seconds > 0 else 0
+    if dist is not None and n_sus:
+        tn = torch.tensor([n_sus], dtype=torch.int64, device=dev)
+        dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+        n_sus = int(tn.item())
+    dt_sus = timed(n_sus) if n_sus else None
 
-    # ---- roofline of the dominant kernel: multi-level RoIAlign 7x7 (box head), HIP events on the launch stream -----
+    # ---- roofline of the dominant kernel: the box-head RoIAlign launch, HIP events on the launch stream -------------------
     iters = a.kernel_iters
     e0 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
     e1 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
-    path._roi_align_box()
+    for p in paths:                          # every path holds the descriptors of its own inputs from its last step
+        p._roi_align_box()
     torch.cuda.synchronize(dev)
     for i in range(iters):
+        p = paths[i % NSETS]
         e0[i].record()
-        path._roi_align_box()
+        p._roi_align_box()
         e1[i].record()
     torch.cuda.synchronize(dev)
     k_ms = float(np.mean([e0[i].elapsed_time(e1[i]) for i in range(iters)]))
-    alg_bytes = path.box_roialign_bytes()
+    alg_bytes = paths[0].box_roialign_bytes()
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
-    traffic = None
-    try:   # HBM bytes per launch of the same kernel/config from the committed rocprofv3 --pmc passes (profiles/README.md)
+    traffic, traffic_src = None, None
+    try:   # HBM-side bytes per launch of the same kernel/config: rocprofv3 --pmc passes, committed (profiles/README.md)
         tj = json.load(open(os.path.join(ROOT, "profiles", "roialign_traffic.json")))
-        key = "b%d_%s_%s" % (a.batch, "nhwc" if a.channels_last else "nchw", "f16" if a.fp16 else "f32")
+        key = "%s_b%d_%s_%s" % (wl, a.batch, "nhwc" if a.channels_last else "nchw", "f16" if fp16 else "f32")
         if key in tj:
-            traffic = tj[key]
+            traffic, traffic_src = tj[key], "profiles/roialign_traffic.json[%s] (rocprofv3 --pmc TCC_EA0_* passes, tools/collect_profiles.sh; not measured in this run)" % key
     except Exception:
-        traffic = None
+        pass
 
     if rank == 0:
         n_img = a.batch * a.steps * world
+        p0 = paths[0]
+        if wl == "cfg2":
+            desc = ("BASELINE configs[1]: Faster R-CNN R-50-C4, 1x3x800x1333, RPN 63000 anchors -> 6000 -> NMS 0.7 -> 1000 proposals, "
+                    "RoIAlign %dx%d sampling_ratio 0 on res4 [B,1024,50,84], 81-class postprocess" % (a.c4_pooled, a.c4_pooled))
+            kern = "roi_align (res4, adaptive sampling, %d rois x 1024 ch)" % (a.batch * 1000)
+            not_in = "ResNet-50 convs, RPN head, res5 head GEMMs/convs (MIOpen/hipBLASLt), outputs synthetic"
+        else:
+            desc = ("BASELINE configs[%d]: Mask R-CNN R-50-FPN, 1x3x800x1333 (padded 800x1344), 5-level RPN (268569 anchors) -> %d rois, "
+                    "4-level RoIAlign 7x7 sr2 C256%s, 81-class postprocess, RoIAlign 14x14 mask branch, 28x28 mask paste"
+                    % (4 if wl == "cfg5" else 2, top_n, " fp16 features" if fp16 else ""))
+            kern = "roi_align (box head, 4 levels, %d rois)" % (a.batch * top_n)
+            not_in = "ResNet-50/FPN convs and box/mask-head GEMMs (MIOpen/hipBLASLt), outputs synthetic"
         out = {
-            "metric": "images/sec Mask R-CNN R-50-FPN 1333x800 (region-proposal hot path)",
+            "metric": "images/sec Mask R-CNN R-50-FPN 1333x800 (region-proposal hot path)" if wl != "cfg2" else
+                      "images/sec Faster R-CNN R-50-C4 1333x800 (region-proposal hot path)",
             "value": round(n_img / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16" if a.fp16 else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: Mask R-CNN R-50-FPN, 1x3x800x1333 (padded 800x1344), 5-level RPN "
-                                   "(268569 anchors) -> 1000 rois, 4-level RoIAlign 7x7 sr2 C256, 81-class postprocess, "
-                                   "RoIAlign 14x14 mask branch, 28x28 mask paste",
-                       "images_per_gpu_per_step": a.batch, "global_batch": a.batch * world, "rois_per_image": 1000,
-                       "feature_layout": "NHWC" if a.channels_last else "NCHW", "launch": ("eager" if a.eager else "hipGraph") + (", %d sub-batches on %d streams" % (a.split, a.split) if isinstance(path, OverlappedRegionPath) else ""),
+            "vs_baseline": None, "dtype": "f16" if fp16 else "f32", "data": "synthetic",
+            "config": {"workload": desc, "workload_id": wl,
+                       "images_per_gpu_per_step": a.batch, "global_batch": a.batch * world, "rois_per_image": top_n,
+                       "input_sets_rotated": NSETS,
+                       "feature_layout": "NHWC" if a.channels_last else "NCHW",
+                       "launch": ("eager" if a.eager else "hipGraph") + (", %d sub-batches on %d streams" % (a.split, a.split) if isinstance(p0, OverlappedRegionPath) else ""),
                        "parallelism": "images sharded over %d GPU(s); all_gather of detections" % world,
-                       "not_in_path": "ResNet-50/FPN convs and box/mask-head GEMMs (MIOpen/hipBLASLt), outputs synthetic"},
-            "roofline": {"bound": "hbm", "kernel": "roi_align_fwd (box head, 4 levels, %d rois)" % (a.batch * 1000),
+                       "not_in_path": not_in},
+            "roofline": {"bound": "hbm", "kernel": kern,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k_ms, 4)},
+            "consistency": {"timed_region_s": round(dt, 4),
+                            "sustained": None if dt_sus is None else {"steps": n_sus, "seconds": round(dt_sus, 3),
+                                                                      "ms_per_step": round(dt_sus / n_sus * 1e3, 4),
+                                                                      "images_per_sec": round(a.batch * n_sus * world / dt_sus, 2)}},
         }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(inputs, path, a.cpu_images)
+        if not a.no_cpu_baseline and world == 1 and not isinstance(p0, OverlappedRegionPath):
+            p0.step(use_graph=not a.eager)          # the configuration that was timed, on input set 0
+            torch.cuda.synchronize(dev)
+            out["cpu_baseline"] = cpu_baseline(wl, inputs[0], p0, a.cpu_images, a.c4_pooled)
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

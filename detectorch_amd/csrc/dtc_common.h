@@ -55,4 +55,19 @@ __device__ __forceinline__ float4 bf16x4_to_f32(uint2 r) {
 
 __host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Zero-fill as a KERNEL node.  hipMemsetAsync must not be used on any path that can be captured into a hipGraph: on ROCm
+// 7.0 / gfx950 a captured memset node followed by kernels that are ALSO launched eagerly between replays was observed to
+// run out of order with them (round 2: stale radix-select histograms after `replay B, eager A, eager B, replay A`).
+template <int kUnused = 0>
+__global__ void zero_words_kernel(uint32_t* p, size_t n_words) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_words) p[i] = 0u;
+}
+inline int zero_async(void* p, size_t bytes, hipStream_t s) {   // bytes: multiple of 4, p 4-byte aligned
+  if (bytes == 0) return DTC_OK;
+  const size_t n = bytes / 4;
+  hipLaunchKernelGGL(zero_words_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), n);
+  return hipGetLastError() == hipSuccess ? DTC_OK : DTC_ELAUNCH;
+}
+
 }  // namespace dtc

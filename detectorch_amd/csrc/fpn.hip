@@ -264,7 +264,7 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
   if (in_scores && inputs_sorted) smem = (size_t)post_nms_top_n * sizeof(uint64_t) + (size_t)n_max * sizeof(float) + 16;
   if (roi_order) { const size_t so = (size_t)(dtc::next_pow2(post_nms_top_n) < 4 ? 4 : dtc::next_pow2(post_nms_top_n)) * sizeof(uint64_t) * 2; if (so > smem) smem = so; }
   if (post_nms_top_n > 16384) return DTC_EUNSUPPORTED;
-  if (smem > 64 * 1024) {
+  if (smem > 32 * 1024) {   // static __shared__ of the kernel comes on top: raise the limit well before dynamic + static reaches 64 KB
     static bool raised = false;
     if (!raised) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::fpn_collect_distribute_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess) return DTC_ELAUNCH;

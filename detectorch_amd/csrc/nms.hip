@@ -264,7 +264,7 @@ DTC_API int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg,
   if (n_seg == 0) return DTC_OK;
   if (!keep_count || (n_stride > 0 && (!boxes || !keep || !workspace))) return DTC_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (n_stride == 0) { return hipMemsetAsync(keep_count, 0, sizeof(int32_t) * n_seg, s) == hipSuccess ? DTC_OK : DTC_ELAUNCH; }
+  if (n_stride == 0) { return dtc::zero_async(keep_count, sizeof(int32_t) * n_seg, s); }
   if (workspace_bytes < dtc_nms_sorted_workspace_bytes(n_seg, n_stride)) return DTC_EWORKSPACE;
   const int ncb = (n_stride + 63) / 64;
   if (ncb > 64 * 4) return DTC_EUNSUPPORTED;  // > 16384 boxes per segment
@@ -294,7 +294,7 @@ DTC_API int dtc_segment_sort_desc(const float* scores, int score_stride_elems, c
   if (!scores || (sorted_boxes && !boxes)) return DTC_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t smem = (size_t)dtc::next_pow2(n_stride) * sizeof(uint64_t);
-  if (smem > 64 * 1024) {
+  if (smem > 32 * 1024) {   // static __shared__ of the kernel comes on top: raise the limit well before dynamic + static reaches 64 KB
     static bool raised = false;
     if (!raised) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::segment_sort_desc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
@@ -321,7 +321,7 @@ DTC_API int dtc_nms(const float* dets, int n, float thresh, void* workspace, siz
                     int32_t* keep_count, dtc_stream_t stream) {
   if (n < 0 || !keep_count) return DTC_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (n == 0) return hipMemsetAsync(keep_count, 0, sizeof(int32_t), s) == hipSuccess ? DTC_OK : DTC_ELAUNCH;  // boxes.py:334-335
+  if (n == 0) return dtc::zero_async(keep_count, sizeof(int32_t), s);  // boxes.py:334-335
   if (n > 16384) return DTC_EUNSUPPORTED;
   if (!dets || !keep_out || !workspace) return DTC_EINVAL;
   if (workspace_bytes < dtc_nms_workspace_bytes(n)) return DTC_EWORKSPACE;
@@ -335,7 +335,7 @@ DTC_API int dtc_nms(const float* dets, int n, float thresh, void* workspace, siz
   rc = dtc_nms_sorted(sboxes, nullptr, 1, n, thresh, 0, w, dtc_nms_sorted_workspace_bytes(1, n), keep, n, cnt, stream);
   if (rc != DTC_OK) return rc;
   const size_t smem = (size_t)dtc::next_pow2(n) * sizeof(uint64_t);
-  if (smem > 64 * 1024) {
+  if (smem > 32 * 1024) {   // static __shared__ of the kernel comes on top: raise the limit well before dynamic + static reaches 64 KB
     static bool raised = false;
     if (!raised) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::nms_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
@@ -461,7 +461,7 @@ DTC_API int dtc_soft_nms(const float* dets, int n, float sigma, float overlap_th
                          float* dets_out, int64_t* inds_out, int32_t* n_out, dtc_stream_t stream) {
   if (n < 0 || !n_out || method < 0 || method > 2) return DTC_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (n == 0) return hipMemsetAsync(n_out, 0, sizeof(int32_t), s) == hipSuccess ? DTC_OK : DTC_ELAUNCH;
+  if (n == 0) return dtc::zero_async(n_out, sizeof(int32_t), s);
   if (n > 6000) return DTC_EUNSUPPORTED;
   if (!dets || !dets_out || !inds_out) return DTC_EINVAL;
   const size_t smem = (size_t)n * (6 * 4 + 1) + 16;

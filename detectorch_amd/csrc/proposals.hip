@@ -408,7 +408,7 @@ DTC_API int dtc_rpn_topk_decode(const dtc_rpn_level* levels, int n_levels, int b
   p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_counts = out_counts;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // histograms + counters are contiguous at the start of the workspace
-  if (hipMemsetAsync(w, 0, plan.off_gt, s) != hipSuccess) return DTC_ELAUNCH;
+  if (dtc::zero_async(w, plan.off_gt, s) != DTC_OK) return DTC_ELAUNCH;     // a kernel node, never hipMemsetAsync (dtc_common.h)
   const dim3 grid(plan.chunks_per_image, batch), blk(dtc::kHistThreads);
   hipLaunchKernelGGL(dtc::rpn_hist_kernel<0>, grid, blk, 0, s, p);
   hipLaunchKernelGGL(dtc::rpn_hist_kernel<1>, grid, blk, 0, s, p);
@@ -417,7 +417,7 @@ DTC_API int dtc_rpn_topk_decode(const dtc_rpn_level* levels, int n_levels, int b
   DTC_CHECK_LAUNCH();
   const int sort_cap = dtc::next_pow2(plan.k_stride) <= 1024 ? 2048 : dtc::next_pow2(plan.k_stride);
   const size_t smem = (size_t)sort_cap * sizeof(uint64_t);
-  if (smem > 64 * 1024) {
+  if (smem > 32 * 1024) {   // static __shared__ of the kernel comes on top: raise the limit well before dynamic + static reaches 64 KB
     static bool raised = false;
     if (!raised) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::rpn_sort_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess) return DTC_ELAUNCH;

@@ -830,7 +830,7 @@ static int launch_nhwc(const RoiAlignParams& p, hipStream_t stream) {
   if (p.n_rois == 0) return DTC_OK;
   const size_t smem = (size_t)kLdsTableFloats * 4 + (size_t)64 * p.pooled_h * p.pooled_w * 4 + 16;
   static bool raised = false;
-  if (!raised && smem > 64 * 1024) {
+  if (!raised && smem > 32 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_nhwc<TIn, TOut>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
     raised = true;

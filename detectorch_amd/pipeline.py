@@ -168,6 +168,113 @@ class FpnRegionPath:
         return out
 
 
+class C4RegionPath:
+    """The region-proposal hot path of the C4 flavour (BASELINE configs[1]: Faster R-CNN R-50-C4, "1000 RPN proposals,
+    RoIAlign 7x7 + NMS only") for a batch of images, device-resident, one hipGraph:
+
+        RPN outputs [B,15,50,84] / [B,60,50,84] --[rpn_topk_decode 63 000 -> 6000, nms_sorted 0.7 -> 1000, gather]-->  generate_proposals.py:31-122
+          --[collect (1 level: rois5 + visiting order)]--> rois5 [B,1000,5]
+          --[roi_align on res4 [B,1024,50,84], adaptive sampling (sampling_ratio 0)]--> [B*1000,1024,P,P]               detector.py:240-248
+          (res5 head + cls/bbox: convs / GEMMs, not part of the hot path -- synthetic outputs)
+          --[postprocess_detections]--> dets [B,128,6]                                                                  result_utils.py:76-168
+    """
+
+    def __init__(self, batch, device, channels=1024, n_cls=81, pre_nms_top_n=6000, post_nms_top_n=1000, rpn_nms_thresh=0.7,
+                 pooled=7, sampling_ratio=0, max_det=100, max_out=128, im_h=synth.IM_H, im_w=synth.IM_W,
+                 feat_dtype=torch.float32):
+        self.B, self.dev, self.C, self.n_cls = batch, device, channels, n_cls
+        self.pre, self.post, self.top_n = pre_nms_top_n, post_nms_top_n, post_nms_top_n
+        self.thresh, self.pooled, self.sr = rpn_nms_thresh, pooled, sampling_ratio
+        self.max_det, self.max_out, self.im_h, self.im_w = max_det, max_out, im_h, im_w
+        self.H, self.W = synth.c4_shape(im_h, im_w)
+        self.anchors = [generate_anchors(stride=16.0)]                                   # 15 anchors, detector.py:197-199
+        self.feat_dtype = feat_dtype
+        self.graph = None
+        B, dev, f32, i32 = batch, device, torch.float32, torch.int32
+        L = hip.lib()
+        e = lambda *shape, dtype=f32: torch.empty(shape, dtype=dtype, device=dev)
+        N = 15 * self.H * self.W
+        self.kmax = min(self.pre, N)
+        self.P = min(self.post, self.kmax)
+        self.pre_boxes, self.pre_scores, self.pre_counts = e(B, self.kmax, 4), e(B, self.kmax), e(B, dtype=i32)
+        self.keep, self.keep_cnt = e(B, self.P, dtype=i32), e(B, dtype=i32)
+        self.prop_boxes, self.prop_scores = torch.zeros((B, self.P, 4), device=dev), torch.zeros((B, self.P), device=dev)
+        self.nms_ws = hip.workspace(L.dtc_nms_sorted_workspace_bytes(B, self.kmax), dev)
+        T = self.top_n
+        self.rois5, self.roi_scores = e(B, T, 5), e(B, T)
+        self.roi_levels, self.n_rois = e(B, T, dtype=i32), e(B, dtype=i32)
+        self.rois_by_level, self.level_counts, self.idx_restore = e(B, T, 4), e(B, 1, dtype=i32), e(B, T, dtype=i32)
+        self.roi_order, self.roi_desc = e(B, T, dtype=i32), e(B, T, 8)
+        self.box_feats = e(B * T, self.C, pooled, pooled, dtype=feat_dtype)
+        D = max_out
+        self.dets, self.det_roi = torch.zeros((B, D, 6), device=dev), torch.zeros((B, D), dtype=i32, device=dev)
+        self.det_scaled, self.det_count = torch.zeros((B, D, 4), device=dev), e(B, dtype=i32)
+        self.det_ws = hip.workspace(L.dtc_postprocess_detections_workspace_bytes(B, T, n_cls), dev)
+
+    def bind(self, rpn_cls, rpn_bbox, feat, cls_score, bbox_pred, scaling_factor, im_size):
+        self.rpn_cls, self.rpn_bbox, self.feat = rpn_cls, rpn_bbox, feat
+        self.cls_score, self.bbox_pred, self.sf, self.im_size = cls_score, bbox_pred, scaling_factor, im_size
+        self.rpn_lv, self._alive = hip.make_rpn_levels([rpn_cls], [rpn_bbox], self.anchors, [16.0], [self.pre])
+        self.rpn_ws = hip.workspace(hip.lib().dtc_rpn_topk_decode_workspace_bytes(self.rpn_lv, 1, self.B, self.kmax), self.dev)
+        self.feat_lv, _, _ = hip.make_levels([feat], [1.0 / 16.0])
+        self.feat_code, self.out_code = hip._dtype_code(feat.dtype), hip._dtype_code(self.feat_dtype)
+        self.graph = None
+
+    def _launch(self):
+        L, B, st, ck = hip.lib(), self.B, hip.stream_ptr(self.dev), hip.check
+        T, D = self.top_n, self.max_out
+        ck(L.dtc_rpn_topk_decode(self.rpn_lv, 1, B, float(self.im_h), float(self.im_w), 0.0, self.rpn_ws.data_ptr(),
+                                 self.rpn_ws.numel(), self.pre_boxes.data_ptr(), self.pre_scores.data_ptr(),
+                                 self.pre_counts.data_ptr(), self.kmax, st), "rpn_topk_decode")
+        ck(L.dtc_nms_sorted(self.pre_boxes.data_ptr(), self.pre_counts.data_ptr(), B, self.kmax, self.thresh, self.P,
+                            self.nms_ws.data_ptr(), self.nms_ws.numel(), self.keep.data_ptr(), self.P,
+                            self.keep_cnt.data_ptr(), st), "nms_sorted")
+        ck(L.dtc_gather_kept(self.pre_boxes.data_ptr(), self.pre_scores.data_ptr(), B, self.kmax, self.keep.data_ptr(),
+                             self.keep_cnt.data_ptr(), self.P, self.prop_boxes.data_ptr(), self.prop_scores.data_ptr(), st),
+           "gather_kept")
+        # one input list per image, already in score order: rois5 (b, box) + the RoIAlign visiting order; k_min == k_max -> level 0
+        ck(L.dtc_fpn_collect_distribute(self.prop_boxes.data_ptr(), self.prop_scores.data_ptr(), self.keep_cnt.data_ptr(),
+                                        B, 1, self.P, T, 4, 4, self.rois5.data_ptr(), self.roi_scores.data_ptr(),
+                                        self.roi_levels.data_ptr(), self.n_rois.data_ptr(), self.rois_by_level.data_ptr(),
+                                        self.level_counts.data_ptr(), self.idx_restore.data_ptr(),
+                                        self.roi_order.data_ptr(), self.roi_desc.data_ptr(), 1, st), "collect")
+        self._roi_align_box(st)
+        ck(L.dtc_postprocess_detections(self.rois5.data_ptr(), self.n_rois.data_ptr(), self.cls_score.data_ptr(),
+                                        self.bbox_pred.data_ptr(), self.sf.data_ptr(), self.im_size.data_ptr(), B, T,
+                                        self.n_cls, 10.0, 10.0, 5.0, 5.0, 0.05, 0.5, self.max_det,
+                                        self.det_ws.data_ptr(), self.det_ws.numel(), self.dets.data_ptr(),
+                                        self.det_roi.data_ptr(), self.det_scaled.data_ptr(), self.det_count.data_ptr(), D, st),
+           "postprocess_detections")
+
+    def _roi_align_box(self, st=None):
+        st = st or hip.stream_ptr(self.dev)
+        hip.check(hip.lib().dtc_roi_align_forward_packed(self.feat_lv, 1, self.C, self.feat_code, self.roi_desc.data_ptr(),
+                                                  self.B * self.top_n, self.pooled, self.pooled, self.sr,
+                                                  self.box_feats.data_ptr(), self.out_code, st), "roi_align(c4)")
+
+    step = FpnRegionPath.step
+
+    def box_roialign_bytes(self):
+        return (self.feat.numel() * self.feat.element_size() + self.B * self.top_n * 5 * 4 +
+                self.box_feats.numel() * self.box_feats.element_size())
+
+
+def synthetic_c4_batch(batch, device, seed, channels=1024, n_cls=81, top_n=1000, feat_dtype=torch.float32):
+    """SURVEY.md section 8(d) cfg2 inputs on the device: argument tuple of C4RegionPath.bind()."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    H, W = synth.c4_shape()
+    rn = lambda *s: torch.randn(s, generator=g, device=device)
+    rpn_cls = torch.sigmoid(rn(batch, 15, H, W) * 2.0 - 2.0)
+    rpn_bbox = rn(batch, 60, H, W) * 0.2
+    feat = torch.relu(rn(batch, channels, H, W)).to(feat_dtype)
+    cls_score = torch.softmax(rn(batch, top_n, n_cls) * 2.0, dim=2).contiguous()
+    bbox_pred = (rn(batch, top_n, 4 * n_cls) * 0.1).contiguous()
+    sf = torch.full((batch,), 1.6, device=device)
+    im_size = torch.tensor([[500.0, 833.0]] * batch, device=device)
+    return rpn_cls, rpn_bbox, feat, cls_score, bbox_pred, sf, im_size
+
+
 class OverlappedRegionPath:
     """The same hot path with the batch split into `n_split` sub-batches that run on separate HIP streams inside ONE
     hipGraph (fork/join).  The path alternates chip-filling RoIAlign launches with short latency-bound kernels (radix

@@ -14,11 +14,12 @@ ROI_SCALES = (0.25, 0.125, 0.0625, 0.03125)
 
 
 def fpn_hot_path(rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, sf, im_size, pad_h, pad_w, pre=1000, post=1000,
-                 top_n=1000, max_det=100, M=28, box_p=7, mask_p=14, sr=2, timings=None):
+                 top_n=1000, max_det=100, M=28, box_p=7, mask_p=14, sr=2, timings=None, roi_align=None):
     """rpn_cls/rpn_bbox: 5 arrays [A,H,W]/[4A,H,W]; feats: 4 arrays [1,C,H,W]; cls_score [top_n,81]; bbox_pred [top_n,324];
     masks [>=D,81,M,M].  Returns a dict of every intermediate the GPU path produces."""
     t = time.perf_counter
     T = {} if timings is None else timings
+    ra = roi_align or orc.roi_align_forward       # bench.py passes the reference-compiled loop (oracle/_ref) when it is there
     t0 = t()
     props, scores = [], []
     for l in range(5):
@@ -36,7 +37,7 @@ def fpn_hot_path(rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, sf, im_s
     for l in range(4):
         m = lv == l + 2
         if m.any():
-            box_feats[m] = orc.roi_align_forward(feats[l], rois5[m], box_p, box_p, ROI_SCALES[l], sr)
+            box_feats[m] = ra(feats[l], rois5[m], box_p, box_p, ROI_SCALES[l], sr)
     T["roi_align_box"] = T.get("roi_align_box", 0) + t() - t0; t0 = t()
     dets, det_roi = orc.postprocess_detections(rois, sf, im_size, cls_score[:n], bbox_pred[:n], max_det=max_det)
     T["postprocess"] = T.get("postprocess", 0) + t() - t0; t0 = t()
@@ -48,7 +49,7 @@ def fpn_hot_path(rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, sf, im_s
     for l in range(4):
         m = mlv == l + 2
         if m.any():
-            mask_feats[m] = orc.roi_align_forward(feats[l], m5[m], mask_p, mask_p, ROI_SCALES[l], sr)
+            mask_feats[m] = ra(feats[l], m5[m], mask_p, mask_p, ROI_SCALES[l], sr)
     T["roi_align_mask"] = T.get("roi_align_mask", 0) + t() - t0; t0 = t()
     crops, boxes = [], []
     for d in range(D):
@@ -102,4 +103,42 @@ def compare_with_gpu(path, b, ref, im_h, im_w, check_masks=True):
             exp = crop[y0 - bx[1]:y1 - bx[1], x0 - bx[0]:x1 - bx[0]]
             got = crops[offs[d]:offs[d] + (x1 - x0) * (y1 - y0)].reshape(y1 - y0, x1 - x0)
             assert np.array_equal(got, exp), d
+    return True
+
+
+def c4_hot_path(rpn_cls, rpn_bbox, feat, cls_score, bbox_pred, sf, im_size, im_h, im_w, pre=6000, post=1000, pooled=7, sr=0,
+                max_det=100, timings=None, roi_align=None):
+    """BASELINE configs[1] (Faster R-CNN R-50-C4) for ONE image: rpn_cls [15,H,W], rpn_bbox [60,H,W], feat [1,C,H,W].
+    Follows lib/model/detector.py:240-248, 273-284 (C4 branch) + lib/utils/result_utils.py:76-168."""
+    t = time.perf_counter
+    T = {} if timings is None else timings
+    ra = roi_align or orc.roi_align_forward
+    t0 = t()
+    anchors = orc.generate_anchors(16.0)
+    rois, scores = orc.generate_proposals(rpn_cls, rpn_bbox, anchors, 16.0, im_h, im_w, pre, post, 0.7)
+    T["generate_proposals"] = T.get("generate_proposals", 0) + t() - t0; t0 = t()
+    n = rois.shape[0]
+    rois5 = np.hstack([np.zeros((n, 1), np.float32), rois])
+    box_feats = ra(feat, rois5, pooled, pooled, 1.0 / 16.0, sr)
+    T["roi_align_box"] = T.get("roi_align_box", 0) + t() - t0; t0 = t()
+    dets, det_roi = orc.postprocess_detections(rois, sf, im_size, cls_score[:n], bbox_pred[:n], max_det=max_det)
+    T["postprocess"] = T.get("postprocess", 0) + t() - t0
+    return dict(rois=rois, roi_scores=scores, box_feats=box_feats, dets=dets, det_roi=det_roi)
+
+
+def compare_c4_with_gpu(path, b, ref):
+    """Image b of a detectorch_amd.pipeline.C4RegionPath after step() == the oracle result (bit-exact everywhere)."""
+    n = int(path.n_rois[b])
+    assert n == ref["rois"].shape[0], (n, ref["rois"].shape)
+    assert np.array_equal(path.rois5[b, :n, 1:].cpu().numpy(), ref["rois"])
+    assert np.array_equal(path.roi_scores[b, :n].cpu().numpy(), ref["roi_scores"])
+    T = path.top_n
+    bf = path.box_feats[b * T:b * T + n].float().cpu().numpy()
+    assert np.abs(bf - ref["box_feats"]).max() <= 1e-4
+    assert np.array_equal(bf, ref["box_feats"])
+    D = int(path.det_count[b])
+    assert D == ref["dets"].shape[0], (D, ref["dets"].shape)
+    D = min(D, path.max_out)
+    assert np.array_equal(path.dets[b, :D].cpu().numpy(), ref["dets"][:D])
+    assert np.array_equal(path.det_roi[b, :D].cpu().numpy(), ref["det_roi"][:D])
     return True

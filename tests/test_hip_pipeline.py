@@ -97,3 +97,26 @@ def test_bench_configuration_vs_oracle_chain(oracle):
                                  host(cls_score[b]), host(bbox_pred[b]), host(masks[b * path.max_out:(b + 1) * path.max_out]),
                                  float(sf[b]), host(im_size[b]), path.pad_h, path.pad_w)
         assert chain.compare_with_gpu(path, b, ref, int(im_size[b, 0]), int(im_size[b, 1]))
+
+
+def test_c4_region_path_vs_oracle_chain(oracle):
+    """BASELINE configs[1] flavour (63 000 anchors -> 6000 -> NMS 0.7 -> 1000 -> RoIAlign on res4, adaptive sampling ->
+    detections), batched + graph-replayed, against the oracle chain: every intermediate bit-exact.  C = 32 keeps the CPU side
+    short; the true C = 1024 RoIAlign shape is covered by test_c4_true_shape_vs_reference_compiled."""
+    import chain
+    from detectorch_amd.pipeline import C4RegionPath, synthetic_c4_batch
+    dev = torch.device("cuda", 0)
+    B, C = 2, 32
+    for pooled in (7, 14):
+        path = C4RegionPath(B, dev, channels=C, pooled=pooled)
+        inputs = synthetic_c4_batch(B, dev, seed=2000, channels=C)
+        path.bind(*inputs)
+        path.step(use_graph=True)
+        path.step(use_graph=True)
+        torch.cuda.synchronize()
+        rpn_cls, rpn_bbox, feat, cls_score, bbox_pred, sf, im_size = [x.cpu().numpy() for x in inputs]
+        for b in range(B):
+            ref = chain.c4_hot_path(rpn_cls[b], rpn_bbox[b], feat[b:b + 1], cls_score[b], bbox_pred[b], sf[b], im_size[b],
+                                    path.im_h, path.im_w, pooled=pooled)
+            assert chain.compare_c4_with_gpu(path, b, ref)
+            assert ref["rois"].shape[0] == 1000 and ref["dets"].shape[0] >= 100
