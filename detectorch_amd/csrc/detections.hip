@@ -19,7 +19,8 @@ constexpr int kDetThreads = 256;
 struct DetParams {
   const float* rois5;        // [B, R, 5]
   const int32_t* n_rois;     // [B] or NULL (all R valid)
-  const float* cls_score;    // [B, R, n_cls]
+  const float* cls_score;    // [B, R, n_cls]  probabilities, or LOGITS when sm_stats != NULL
+  const double* sm_stats;    // [B, R, 2] = (row max, sum_j exp(l_j - max)) of the class logits, or NULL
   const float* bbox_pred;    // [B, R, 4*n_cls]
   const float* scale;        // [B] scaling factor per image
   const float* im_size;      // [B, 2] original (h, w)
@@ -52,6 +53,29 @@ __device__ __forceinline__ void decode_det(const float roi[4], float sf, const f
   out[2] = fmaxf(fminf(b2, im_w - 1.f), 0.f); out[3] = fmaxf(fminf(b3, im_h - 1.f), 0.f);
 }
 
+// ---- box-head epilogue fusion: class scores handed over as LOGITS -----------------------------------------
+// The reference applies F.softmax to the cls_score layer's output (lib/model/detector.py:281) and hands the [R,81]
+// probability map to postprocess_output.  Here the probability is formed where it is consumed: one wave per roi row
+// reduces (max, sum of exp) once -- 16 bytes per roi instead of a second [R,81] map -- and det_candidates evaluates
+//     prob[r,j] = float( exp(double(l[r,j]) - max_r) / sum_r )
+// for the one class column it scans.  Evaluated in double and rounded once, the sum taken in a FIXED order (element j goes
+// to slot j % 64 in increasing j, then a 64 -> 1 halving tree), so that oracle/oracle.py:softmax_rows gives the same bits;
+// torch's float32 softmax agrees with it to rel 1e-6 (tests/test_oracle_golden.py).
+__global__ __launch_bounds__(kDetThreads) void det_softmax_stats_kernel(const float* logits, int n_rows, int n_cls, double* stats) {
+  const int row = blockIdx.x * (kDetThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const float* l = logits + (size_t)row * n_cls;
+  float m = -INFINITY;
+  for (int j = lane; j < n_cls; j += 64) m = fmaxf(m, l[j]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  double e = 0.0;
+  for (int j = lane; j < n_cls; j += 64) e += exp((double)l[j] - (double)m);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off, 64);       // lane 0: ((s0+s32)+(s16+s48))+... halving tree
+  if (lane == 0) { stats[(size_t)row * 2] = (double)m; stats[(size_t)row * 2 + 1] = e; }
+}
+
 __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
@@ -71,7 +95,14 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
     const int r = r0 + tid;
     float s = 0.f;
     bool ok = false;
-    if (r < nr) { s = sc[(size_t)r * p.n_cls]; ok = s > p.score_thresh; }
+    if (r < nr) {
+      s = sc[(size_t)r * p.n_cls];
+      if (p.sm_stats) {      // logits in: softmax column formed here (detector.py:281)
+        const double* st = p.sm_stats + ((size_t)b * p.R + r) * 2;
+        s = (float)(exp((double)s - st[0]) / st[1]);
+      }
+      ok = s > p.score_thresh;
+    }
     const uint64_t m = __ballot(ok);
     if (lane == 0) wave_tot[wv] = __builtin_popcountll(m);
     __syncthreads();
@@ -282,7 +313,7 @@ extern "C" int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_s
                               int32_t* keep_count, dtc_stream_t stream);
 
 namespace dtc {
-struct DetPlan { size_t sorted_boxes, q_of_k, q_boxes, q_scores, q_roi, cand_count, keep, keep_count, nms, total; };
+struct DetPlan { size_t sorted_boxes, q_of_k, q_boxes, q_scores, q_roi, cand_count, keep, keep_count, sm_stats, nms, total; };
 static DetPlan det_plan(int batch, int R, int n_cls) {
   DetPlan d;
   const size_t S = (size_t)batch * (n_cls - 1);
@@ -295,6 +326,7 @@ static DetPlan det_plan(int batch, int R, int n_cls) {
   d.cand_count = o; o += al256(S * sizeof(int32_t));
   d.keep = o; o += al256(S * R * sizeof(int32_t));
   d.keep_count = o; o += al256(S * sizeof(int32_t));
+  d.sm_stats = o; o += al256((size_t)batch * R * 2 * sizeof(double));
   d.nms = o; o += dtc_nms_sorted_workspace_bytes((int)S, R);
   d.total = o;
   return d;
@@ -306,7 +338,7 @@ DTC_API size_t dtc_postprocess_detections_workspace_bytes(int batch, int max_roi
   return dtc::det_plan(batch, max_rois, n_cls).total;
 }
 
-DTC_API int dtc_postprocess_detections(const float* rois5, const int32_t* n_rois, const float* cls_score,
+static int postprocess_detections_impl(const float* rois5, const int32_t* n_rois, const float* cls_score, int scores_are_logits,
                                        const float* bbox_pred, const float* scaling_factor, const float* im_size,
                                        int batch, int max_rois, int n_cls, float wx, float wy, float ww, float wh,
                                        float score_thresh, float nms_thresh, int max_det, void* workspace,
@@ -324,6 +356,15 @@ DTC_API int dtc_postprocess_detections(const float* rois5, const int32_t* n_rois
   const int S = batch * (n_cls - 1);
   dtc::DetParams p;
   p.rois5 = rois5; p.n_rois = n_rois; p.cls_score = cls_score; p.bbox_pred = bbox_pred; p.scale = scaling_factor;
+  p.sm_stats = nullptr;
+  if (scores_are_logits) {
+    double* st = reinterpret_cast<double*>(w + pl.sm_stats);
+    const int rows = batch * max_rois;
+    hipLaunchKernelGGL(dtc::det_softmax_stats_kernel, dim3((rows + dtc::kDetThreads / 64 - 1) / (dtc::kDetThreads / 64)),
+                       dim3(dtc::kDetThreads), 0, s, cls_score, rows, n_cls, st);
+    DTC_CHECK_LAUNCH();
+    p.sm_stats = st;
+  }
   p.im_size = im_size; p.R = max_rois; p.n_cls = n_cls; p.wx = wx; p.wy = wy; p.ww = ww; p.wh = wh;
   p.score_thresh = score_thresh;
   p.sorted_boxes = reinterpret_cast<float*>(w + pl.sorted_boxes); p.q_of_k = reinterpret_cast<int32_t*>(w + pl.q_of_k);
@@ -344,4 +385,26 @@ DTC_API int dtc_postprocess_detections(const float* rois5, const int32_t* n_rois
   hipLaunchKernelGGL(dtc::det_finalize_kernel, dim3(batch), dim3(dtc::kFinThreads), 0, s, f);
   DTC_CHECK_LAUNCH();
   return DTC_OK;
+}
+
+DTC_API int dtc_postprocess_detections(const float* rois5, const int32_t* n_rois, const float* cls_score,
+                                       const float* bbox_pred, const float* scaling_factor, const float* im_size,
+                                       int batch, int max_rois, int n_cls, float wx, float wy, float ww, float wh,
+                                       float score_thresh, float nms_thresh, int max_det, void* workspace,
+                                       size_t workspace_bytes, float* dets, int32_t* det_roi, float* det_rois_scaled,
+                                       int32_t* det_count, int max_out, dtc_stream_t stream) {
+  return postprocess_detections_impl(rois5, n_rois, cls_score, 0, bbox_pred, scaling_factor, im_size, batch, max_rois, n_cls, wx,
+                                     wy, ww, wh, score_thresh, nms_thresh, max_det, workspace, workspace_bytes, dets, det_roi,
+                                     det_rois_scaled, det_count, max_out, stream);
+}
+
+DTC_API int dtc_postprocess_detections_logits(const float* rois5, const int32_t* n_rois, const float* cls_logits,
+                                              const float* bbox_pred, const float* scaling_factor, const float* im_size,
+                                              int batch, int max_rois, int n_cls, float wx, float wy, float ww, float wh,
+                                              float score_thresh, float nms_thresh, int max_det, void* workspace,
+                                              size_t workspace_bytes, float* dets, int32_t* det_roi, float* det_rois_scaled,
+                                              int32_t* det_count, int max_out, dtc_stream_t stream) {
+  return postprocess_detections_impl(rois5, n_rois, cls_logits, 1, bbox_pred, scaling_factor, im_size, batch, max_rois, n_cls, wx,
+                                     wy, ww, wh, score_thresh, nms_thresh, max_det, workspace, workspace_bytes, dets, det_roi,
+                                     det_rois_scaled, det_count, max_out, stream);
 }

@@ -85,6 +85,8 @@ def lib():
     L.dtc_postprocess_detections_workspace_bytes.restype = sz
     L.dtc_postprocess_detections.argtypes = [p, p, p, p, p, p, i, i, i, f, f, f, f, f, f, i, p, sz, p, p, p, p, i, p]
     L.dtc_postprocess_detections.restype = i
+    L.dtc_postprocess_detections_logits.argtypes = L.dtc_postprocess_detections.argtypes
+    L.dtc_postprocess_detections_logits.restype = i
     L.dtc_mask_paste.argtypes = [p, p, i, i, p, p, p, i, i, f, i, p, ll, p, p, p, p, p]
     L.dtc_mask_paste.restype = i
     L.dtc_mask_rle.argtypes = [p, ll, p, p, p, p, i, i, p, i, p, p, i, p, p]
@@ -334,8 +336,10 @@ def fpn_collect_distribute(boxes, scores, counts, post_nms_top_n, k_min=2, k_max
 
 
 def postprocess_detections(rois5, n_rois, cls_score, bbox_pred, scaling_factor, im_size, weights=(10., 10., 5., 5.),
-                           score_thresh=0.05, nms_thresh=0.5, max_det=100, max_out=None, ws=None):
+                           score_thresh=0.05, nms_thresh=0.5, max_det=100, max_out=None, ws=None, scores_are_logits=False):
     """dtc_postprocess_detections.  rois5 [B,R,5], cls_score [B,R,C], bbox_pred [B,R,4C], scaling_factor [B], im_size [B,2].
+    scores_are_logits=True: cls_score holds the raw cls_score-layer output and the softmax of detector.py:281 is folded into
+    the kernel (dtc_postprocess_detections_logits); the probability map is never materialised.
     -> (dets [B,max_out,6], det_roi [B,max_out], det_rois_scaled [B,max_out,4], det_count [B])"""
     dev = _require_cuda(rois5, n_rois, cls_score, bbox_pred, scaling_factor, im_size)
     B, R, ncls = cls_score.shape
@@ -353,7 +357,8 @@ def postprocess_detections(rois5, n_rois, cls_score, bbox_pred, scaling_factor, 
     rois5, cls_score, bbox_pred = rois5.contiguous(), cls_score.contiguous(), bbox_pred.contiguous()
     scaling_factor, im_size = scaling_factor.to(f32).contiguous(), im_size.to(f32).contiguous()
     with torch.cuda.device(dev):
-        rc = L_.dtc_postprocess_detections(rois5.data_ptr(), _ptr(n_rois), cls_score.data_ptr(), bbox_pred.data_ptr(),
+        fn = L_.dtc_postprocess_detections_logits if scores_are_logits else L_.dtc_postprocess_detections
+        rc = fn(rois5.data_ptr(), _ptr(n_rois), cls_score.data_ptr(), bbox_pred.data_ptr(),
                                            scaling_factor.data_ptr(), im_size.data_ptr(), B, R, ncls,
                                            *[float(w) for w in weights], float(score_thresh), float(nms_thresh),
                                            int(max_det), ws.data_ptr(), ws.numel(), dets.data_ptr(), det_roi.data_ptr(),

@@ -13,6 +13,10 @@ Differences from the reference:
     (detector.py:251-270);
   * `channels_last=True` keeps the backbone features NHWC (same logical shape), the layout the RoIAlign kernel reads
     with full cache lines;
+  * `forward_batched(images[B], ...)` (not in the reference, which is batch-1: eval_mask_FPN.ipynb:93) runs backbone ->
+    region path -> heads -> detections -> mask branch for B images with no host round trip, on the same fused batched
+    kernels bench.py measures (detectorch_amd.pipeline.FpnRegionPath); `forward` stays the reference's batch-1 call;
+  * `head_dtype=torch.bfloat16`: RoIAlign writes the pooled features in bf16 and fc6/fc7 run as bf16 MFMA GEMMs;
   * inference only (the reference's README.md:3 scope).
 """
 import pickle
@@ -210,9 +214,13 @@ class detector(nn.Module):
                  conv_head_layers=['layer4', 'avgpool'], fpn_layers=[], fpn_extra_lvl=True, use_rpn_head=False,
                  use_mask_head=False, mask_head_type='upshare', roi_feature_channels=2048, N_classes=81,
                  detector_pkl_file=None, base_cnn_pkl_file=None, output_prob=True, roi_height=14, roi_width=14,
-                 roi_spatial_scale=0.0625, roi_sampling_ratio=0, channels_last=False, fuse_rpn_sigmoid=True):
+                 roi_spatial_scale=0.0625, roi_sampling_ratio=0, channels_last=False, fuse_rpn_sigmoid=True,
+                 head_dtype=None):
         super().__init__()
         self.fuse_rpn_sigmoid = bool(fuse_rpn_sigmoid)   # extension: RPN sigmoid folded into the top-k kernel (same outputs)
+        self.head_dtype = head_dtype    # extension: torch.bfloat16 / float16 -> pooled features + fc6/fc7 in that dtype (MFMA GEMMs)
+        self.N_classes = N_classes
+        self._paths = {}
         if train:
             raise NotImplementedError("detectorch_amd.detector is inference-only")
         self.roi_height, self.roi_width = int(roi_height), int(roi_width)
@@ -290,12 +298,20 @@ class detector(nn.Module):
             roi_features = RoIAlignFunction.apply(img_features, preprocess_rois(rois), self.roi_height, self.roi_width,
                                                   self.roi_spatial_scale, self.roi_sampling_ratio)
         elif fused is not None:
+            # the packed descriptors carry the visiting order (level, row band, x) the cluster-stationary RoIAlign kernel wants;
+            # output rows stay in collected (score) order = the "restored" order of :269-270.  One host sync (the proposal
+            # count) is what the reference-shaped return value costs; forward_batched() has none.
+            T = fused["rois5"].shape[1]
+            odt = self.head_dtype or torch.float32
+            roi_features = torch.empty((T, img_features[0].shape[1], self.roi_height, self.roi_width), dtype=odt, device=image.device)
+            lvs, ch, dt = hip.make_levels(list(img_features), self.roi_spatial_scale)
+            hip.check(hip.lib().dtc_roi_align_forward_packed(lvs, len(self.roi_spatial_scale), ch, hip._dtype_code(dt),
+                                                             fused["roi_desc"].data_ptr(), T, self.roi_height, self.roi_width,
+                                                             self.roi_sampling_ratio, roi_features.data_ptr(), hip._dtype_code(odt),
+                                                             hip.stream_ptr(image.device)), "roi_align(packed)")
             n = int(fused["n_out"][0].item())
-            rois5 = fused["rois5"][0, :n]
-            roi_features = hip.roi_align_forward(list(img_features), self.roi_spatial_scale, rois5, self.roi_height,
-                                                 self.roi_width, self.roi_sampling_ratio,
-                                                 roi_levels=fused["roi_levels"][0, :n])
-            rois = rois5[:, 1:]                                   # already in the "restored" order of :269-270
+            roi_features = roi_features[:n]
+            rois = fused["rois5"][0, :n, 1:]
         else:
             # FPN with precomputed per-level rois (eval_fast_FPN flow): per-level lists + restore index from the caller
             lvs = [torch.full((r.shape[0],), i, dtype=torch.int32, device=r.device) for i, r in enumerate(rois)]
@@ -304,13 +320,84 @@ class detector(nn.Module):
                                                  self.roi_width, self.roi_sampling_ratio, roi_levels=torch.cat(lvs, 0))
             roi_features = roi_features[roi_original_idx, :]
             rois = cat[roi_original_idx, 1:]
-        roi_features = self.conv_head(roi_features)
-        roi_features = roi_features.reshape(roi_features.size(0), -1)
+        roi_features = self._head(roi_features)
         cls_score = self.classif_head(roi_features)
         if self.output_prob:
             cls_score = F.softmax(cls_score, dim=1)
         bbox_pred = self.bbox_head(roi_features)
         return cls_score, bbox_pred, rois, img_features
+
+    def _head(self, roi_features):
+        """conv_head (fc6/fc7 or res5) on pooled features; head_dtype runs it as a low-precision MFMA GEMM, fp32 out."""
+        if self.head_dtype is not None and self.head_dtype != torch.float32:
+            with torch.autocast("cuda", dtype=self.head_dtype):
+                x = self.conv_head(roi_features.to(self.head_dtype))
+            x = x.float()
+        else:
+            x = self.conv_head(roi_features.float() if roi_features.dtype != torch.float32 else roi_features)
+        return x.reshape(x.size(0), -1)
+
+    # ---- batched entry: B images, zero host round trips ------------------------------------------------------------------
+    def _region_path(self, B, h, w, dev):
+        from ..pipeline import FpnRegionPath
+        key = (B, h, w, str(dev))
+        if key not in self._paths:
+            self._paths[key] = FpnRegionPath(B, dev, channels=256, n_cls=self.N_classes, pad_h=h, pad_w=w, cls_logits=True,
+                                             with_rle=self.use_mask_head, box_pooled=self.roi_height, mask_pooled=14,
+                                             sampling_ratio=self.roi_sampling_ratio,
+                                             feat_dtype=self.head_dtype or torch.float32)
+        return self._paths[key]
+
+    @torch.no_grad()
+    def forward_batched(self, images, scaling_factor, im_size):
+        """Mask / Faster R-CNN FPN forward for a BATCH (lib/model/detector.py:233-286 + :99-112 + eval_mask_FPN.ipynb:231-262,
+        which the reference runs image by image with 21 synchronising copies each).
+          images [B,3,H,W] prepared blobs of one padded size (utils.blob.im_list_to_blob); scaling_factor [B]; im_size [B,2]
+          = original (h, w) per image.
+        Everything stays on the device:  backbone(B) -> RPN heads -> FpnRegionPath.launch_proposals (top-k, NMS, collect,
+        distribute, RoIAlign 7x7 in visiting order) -> fc6/fc7/cls/bbox -> launch_detections (softmax folded in, class decode,
+        80-class NMS, top-100, mask-branch RoIAlign 14x14) -> mask head convs -> launch_masks (paste, binarise, COCO RLE).
+        Returns the FpnRegionPath holding the fixed-shape device results (dets [B,128,6], det_count [B], rois5 [B,1000,5],
+        n_rois [B], crops / RLE strings ...) plus the head outputs; `per_image(b)` gives the reference's forward() tuple."""
+        if not (self.use_rpn_head and self.use_fpn_body and self.use_two_layer_mlp_head):
+            raise NotImplementedError("forward_batched covers the FPN configurations (e2e_faster/mask_rcnn_R-*-FPN)")
+        B, h, w = images.size(0), images.size(2), images.size(3)
+        dev = images.device
+        if self.channels_last:
+            images = images.contiguous(memory_format=torch.channels_last)
+        img_features = self.conv_body(images)
+        feats = list(img_features)
+        rpn_in = feats + ([F.max_pool2d(feats[-1], 1, stride=2)] if self.fpn_extra_lvl else [])
+        cls_bbox = [self.rpn(f, logits=self.fuse_rpn_sigmoid) for f in rpn_in]
+        path = self._region_path(B, h, w, dev)
+        path.bind_rpn([c.contiguous() for c, _ in cls_bbox], [b.contiguous() for _, b in cls_bbox], feats,
+                      scores_are_logits=self.fuse_rpn_sigmoid)
+        path.launch_proposals()
+        x = self._head(path.box_feats)                                              # [B*1000, 1024]
+        T = path.top_n
+        cls_logits = self.classif_head(x).reshape(B, T, -1).contiguous()
+        bbox_pred = self.bbox_head(x).reshape(B, T, -1).contiguous()
+        sf = torch.as_tensor(scaling_factor, dtype=torch.float32, device=dev).reshape(B).contiguous()
+        sz = torch.as_tensor(im_size, dtype=torch.float32, device=dev).reshape(B, 2).contiguous()
+        path.bind_heads(cls_logits, bbox_pred, sf, sz)
+        path.launch_detections()
+        path.img_features, path.cls_logits_out, path.bbox_pred_out = img_features, cls_logits, bbox_pred
+        if self.use_mask_head:
+            mh = self.mask_head
+            m = mh.conv_head(path.mask_feats.float() if path.mask_feats.dtype != torch.float32 else path.mask_feats)
+            m = mh.classif_logits(mh.relu(mh.transposed_conv(m)))
+            path.bind_masks(torch.sigmoid(m).contiguous())                          # [B*128, 81, 28, 28]
+            path.launch_masks()
+        return path
+
+    @staticmethod
+    def per_image(path, b):
+        """The reference forward()'s tuple for image b of a forward_batched() result: (cls_score [n,81] probabilities,
+        bbox_pred [n,324], rois [n,4], img_features of that image).  Syncs (one count) -- for callers that want the
+        reference's shapes; the fixed-shape tensors on `path` need no sync."""
+        n = int(path.n_rois[b].item())
+        return (F.softmax(path.cls_logits_out[b, :n], dim=1), path.bbox_pred_out[b, :n], path.rois5[b, :n, 1:],
+                [f[b:b + 1] for f in path.img_features])
 
     # ---- caffe2 / Detectron pickle import (detector.py:289-374) -------------------------------------------------------
     def load_pretrained_weights(self, caffe_pkl_file, model='detector'):

@@ -25,8 +25,11 @@ class FpnRegionPath:
     def __init__(self, batch, device, channels=256, n_cls=81, pre_nms_top_n=1000, post_nms_top_n=1000,
                  collect_top_n=1000, rpn_nms_thresh=0.7, max_det=100, max_out=128, mask_res=28,
                  box_pooled=7, mask_pooled=14, sampling_ratio=2, pad_h=synth.FPN_PAD_H, pad_w=synth.FPN_PAD_W,
-                 feat_dtype=torch.float32, crop_capacity=8 << 20):
+                 feat_dtype=torch.float32, crop_capacity=8 << 20, cls_logits=False, with_rle=False,
+                 rle_runs_stride=4096, rle_str_stride=8192):
         self.B, self.dev = batch, device
+        self.with_rle, self.rle_runs_stride, self.rle_str_stride = with_rle, int(rle_runs_stride), int(rle_str_stride)
+        self.cls_logits = cls_logits       # bind() receives the cls_score layer's raw output; softmax folded into the kernel
         self.C, self.n_cls = channels, n_cls
         self.pre, self.post, self.top_n = pre_nms_top_n, post_nms_top_n, collect_top_n
         self.rpn_thresh, self.max_det, self.max_out, self.M = rpn_nms_thresh, max_det, max_out, mask_res
@@ -72,25 +75,48 @@ class FpnRegionPath:
         self.crops = torch.empty((B, self.crop_capacity), dtype=torch.uint8, device=dev)
         self.mask_boxes, self.mask_rects = torch.zeros((B, D, 4), dtype=i32, device=dev), torch.zeros((B, D, 4), dtype=i32, device=dev)
         self.mask_offsets, self.mask_bytes = torch.zeros((B, D), dtype=torch.int64, device=dev), torch.zeros((B,), dtype=torch.int64, device=dev)
+        if self.with_rle:    # COCO RLE of every pasted mask, on the device (dtc_mask_rle): ~100 bytes per mask leave the GPU
+            self.rle_counts = e(B, D, self.rle_runs_stride, dtype=i32)
+            self.rle_n_runs, self.rle_str_len = torch.zeros((B, D), dtype=i32, device=dev), torch.zeros((B, D), dtype=i32, device=dev)
+            self.rle_str = torch.zeros((B, D, self.rle_str_stride), dtype=torch.uint8, device=dev)
 
     def bind(self, rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, scaling_factor, im_size):
         """Attach the (device) inputs of one batch.  Pointers are baked into the launch descriptors (and the graph), so
         new data is COPIED into these tensors between steps, like any static-shape serving loop."""
-        B = self.B
+        self.bind_rpn(rpn_cls, rpn_bbox, feats)
+        self.bind_heads(cls_score, bbox_pred, scaling_factor, im_size)
+        self.bind_masks(masks)
+
+    # The three stages can also be bound / launched one by one by a model that runs its head GEMMs / convs in between
+    # (detectorch_amd.model.detector.forward_batched):  launch_proposals -> box head -> launch_detections -> mask head ->
+    # launch_masks.
+    def bind_rpn(self, rpn_cls, rpn_bbox, feats, scores_are_logits=False):
         self.rpn_cls, self.rpn_bbox, self.feats = rpn_cls, rpn_bbox, feats
-        self.cls_score, self.bbox_pred, self.masks = cls_score, bbox_pred, masks
-        self.sf, self.im_size = scaling_factor, im_size
-        self.rpn_lv, self._alive = hip.make_rpn_levels(rpn_cls, rpn_bbox, self.anchors, self.strides, [self.pre] * 5)
-        self.rpn_ws = hip.workspace(hip.lib().dtc_rpn_topk_decode_workspace_bytes(self.rpn_lv, 5, B, self.kmax), self.dev)
+        self.rpn_lv, self._alive = hip.make_rpn_levels(rpn_cls, rpn_bbox, self.anchors, self.strides, [self.pre] * 5,
+                                                       scores_are_logits=scores_are_logits)
+        need = hip.lib().dtc_rpn_topk_decode_workspace_bytes(self.rpn_lv, 5, self.B, self.kmax)
+        if getattr(self, "rpn_ws", None) is None or self.rpn_ws.numel() < need:
+            self.rpn_ws = hip.workspace(need, self.dev)
         self.feat_lv, _, _ = hip.make_levels(feats, self.roi_scales)
         self.feat_code = hip._dtype_code(feats[0].dtype)
         self.out_code = hip._dtype_code(self.feat_dtype)
         self.graph = None
 
+    def bind_heads(self, cls_score, bbox_pred, scaling_factor, im_size):
+        self.cls_score, self.bbox_pred = cls_score, bbox_pred
+        self.sf, self.im_size = scaling_factor, im_size
+        self.graph = None
+
+    def bind_masks(self, masks):
+        self.masks = masks
+        self.graph = None
+
     # ---- one pass of the hot path over the bound batch ---------------------------------------------------------------
-    def _launch(self):
-        L, B, st, ck = hip.lib(), self.B, hip.stream_ptr(self.dev), hip.check
-        S, T, D = B * 5, self.top_n, self.max_out
+    def launch_proposals(self, st=None):
+        """RPN outputs -> rois5 / level ids / visiting order -> box-head features (self.box_feats [B*T, C, 7, 7])."""
+        L, B, ck = hip.lib(), self.B, hip.check
+        st = st or hip.stream_ptr(self.dev)
+        S, T = B * 5, self.top_n
         ck(L.dtc_rpn_topk_decode(self.rpn_lv, 5, B, float(self.pad_h), float(self.pad_w), 0.0, self.rpn_ws.data_ptr(),
                                  self.rpn_ws.numel(), self.pre_boxes.data_ptr(), self.pre_scores.data_ptr(),
                                  self.pre_counts.data_ptr(), self.kmax, st), "rpn_topk_decode")
@@ -106,11 +132,18 @@ class FpnRegionPath:
                                         self.level_counts.data_ptr(), self.idx_restore.data_ptr(),
                                         self.roi_order.data_ptr(), self.roi_desc.data_ptr(), 1, st), "fpn_collect")
         self._roi_align_box(st)
-        ck(L.dtc_postprocess_detections(self.rois5.data_ptr(), self.n_rois.data_ptr(), self.cls_score.data_ptr(),
-                                        self.bbox_pred.data_ptr(), self.sf.data_ptr(), self.im_size.data_ptr(), B, T,
-                                        self.n_cls, 10.0, 10.0, 5.0, 5.0, 0.05, 0.5, self.max_det,
-                                        self.det_ws.data_ptr(), self.det_ws.numel(), self.dets.data_ptr(),
-                                        self.det_roi.data_ptr(), self.det_scaled.data_ptr(), self.det_count.data_ptr(), D, st),
+
+    def launch_detections(self, st=None):
+        """cls_score (probabilities, or logits with cls_logits=True) + bbox_pred -> dets -> mask-head features."""
+        L, B, ck = hip.lib(), self.B, hip.check
+        st = st or hip.stream_ptr(self.dev)
+        T, D = self.top_n, self.max_out
+        post = L.dtc_postprocess_detections_logits if self.cls_logits else L.dtc_postprocess_detections
+        ck(post(self.rois5.data_ptr(), self.n_rois.data_ptr(), self.cls_score.data_ptr(),
+                self.bbox_pred.data_ptr(), self.sf.data_ptr(), self.im_size.data_ptr(), B, T,
+                self.n_cls, 10.0, 10.0, 5.0, 5.0, 0.05, 0.5, self.max_det,
+                self.det_ws.data_ptr(), self.det_ws.numel(), self.dets.data_ptr(),
+                self.det_roi.data_ptr(), self.det_scaled.data_ptr(), self.det_count.data_ptr(), D, st),
            "postprocess_detections")
         # mask branch: level ids of the (scaled) detection boxes, multilevel_rois.py:19-39
         ck(L.dtc_fpn_collect_distribute(self.det_scaled.data_ptr(), None, self.det_count.data_ptr(), B, 1, D, D, 2, 5,
@@ -119,10 +152,27 @@ class FpnRegionPath:
                                         self.m_restore.data_ptr(), self.m_order.data_ptr(), self.m_desc.data_ptr(), 0, st),
            "fpn_map_levels")
         self._roi_align_mask(st)
+
+    def launch_masks(self, st=None):
+        """mask-head outputs [B*D, n_cls, M, M] -> binarised crops (+ COCO RLE strings on the device with with_rle=True)."""
+        L, B, ck = hip.lib(), self.B, hip.check
+        st = st or hip.stream_ptr(self.dev)
+        D = self.max_out
         ck(L.dtc_mask_paste(self.masks.data_ptr(), None, self.n_cls, self.M, self.dets.data_ptr(), self.det_count.data_ptr(),
                             self.im_size.data_ptr(), B, D, 0.5, 1, self.crops.data_ptr(), self.crop_capacity,
                             self.mask_boxes.data_ptr(), self.mask_rects.data_ptr(), self.mask_offsets.data_ptr(),
                             self.mask_bytes.data_ptr(), st), "mask_paste")
+        if self.with_rle:
+            ck(L.dtc_mask_rle(self.crops.data_ptr(), self.crop_capacity, self.mask_rects.data_ptr(), self.mask_offsets.data_ptr(),
+                              self.det_count.data_ptr(), self.im_size.data_ptr(), B, D, self.rle_counts.data_ptr(),
+                              self.rle_runs_stride, self.rle_n_runs.data_ptr(), self.rle_str.data_ptr(), self.rle_str_stride,
+                              self.rle_str_len.data_ptr(), st), "mask_rle")
+
+    def _launch(self):
+        st = hip.stream_ptr(self.dev)
+        self.launch_proposals(st)
+        self.launch_detections(st)
+        self.launch_masks(st)
 
     def _roi_align_box(self, st=None):
         st = st or hip.stream_ptr(self.dev)

@@ -135,3 +135,14 @@ def box_voting(top_dets, all_dets, thresh, scoring_method='ID', beta=1.0):
             soft = np.exp(logit / beta)
             out[k, 4] = (soft / np.sum(soft, axis=0))[0].mean()
     return out
+
+
+def xyxy_to_xywh(xyxy):
+    """lib/utils/boxes.py:110-123: [x1 y1 x2 y2] -> [x1 y1 w h] (w = x2 - x1 + 1)."""
+    if isinstance(xyxy, (list, tuple)):
+        assert len(xyxy) == 4
+        x1, y1 = xyxy[0], xyxy[1]
+        return (x1, y1, xyxy[2] - x1 + 1, xyxy[3] - y1 + 1)
+    if isinstance(xyxy, np.ndarray):
+        return np.hstack((xyxy[:, 0:2], xyxy[:, 2:4] - xyxy[:, 0:2] + 1))
+    raise TypeError('Argument xyxy must be a list, tuple, or numpy array.')

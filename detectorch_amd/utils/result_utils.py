@@ -5,6 +5,9 @@ the arithmetic done by the HIP kernels (detectorch_amd/csrc/detections.hip, nms.
     box_results_with_nms_and_limit  result_utils.py:96-168   (hard NMS, Soft-NMS, optional bbox voting)
     segm_results                    result_utils.py:170-228  (RLE on the device: dtc_mask_rle)
     empty_results / extend_results  result_utils.py:32-60
+    assemble_results                the eval loop's per-image empty_results / extend_results bookkeeping (eval_mask_FPN.ipynb
+                                    cell 6) for a whole (gathered) batch of fixed-shape device results
+    coco_bbox_results / coco_segm_results   the records of lib/utils/json_dataset_evaluator.py:67-113, 149-190
 """
 import numpy as np
 import torch
@@ -55,8 +58,11 @@ def _split_by_class(dets, n, num_classes):
     return dets[:, 4].copy(), np.ascontiguousarray(dets[:, :4]), cls_boxes
 
 
-def postprocess_output(rois, scaling_factor, im_size, class_scores, bbox_deltas, bbox_reg_weights=(10.0, 10.0, 5.0, 5.0)):
-    """result_utils.py:76-94 -> (scores_final [D], boxes_final [D,4], boxes_per_class list[81] of [d_j,5])."""
+def postprocess_output(rois, scaling_factor, im_size, class_scores, bbox_deltas, bbox_reg_weights=(10.0, 10.0, 5.0, 5.0),
+                       class_scores_are_logits=False):
+    """result_utils.py:76-94 -> (scores_final [D], boxes_final [D,4], boxes_per_class list[81] of [d_j,5]).
+    class_scores_are_logits=True (not in the reference): `class_scores` is the raw output of the cls_score layer and the
+    F.softmax of lib/model/detector.py:281 is folded into the detection kernel."""
     dev = _dev(rois, class_scores, bbox_deltas)
     rois = _t(rois, dev)
     if rois.dim() == 3:
@@ -69,10 +75,12 @@ def postprocess_output(rois, scaling_factor, im_size, class_scores, bbox_deltas,
     sf = _t(scaling_factor, dev).reshape(-1)[:1]
     sz = _t(im_size, dev).reshape(-1)[:2].reshape(1, 2)
     dets, _, _, cnt = hip.postprocess_detections(rois5, None, cls, dl, sf, sz, weights=bbox_reg_weights,
-                                                 max_out=max(R * (n_cls - 1), 1) if R * (n_cls - 1) <= 4096 else 4096)
+                                                 max_out=max(R * (n_cls - 1), 1) if R * (n_cls - 1) <= 4096 else 4096,
+                                                 scores_are_logits=class_scores_are_logits)
     n = int(cnt[0].item())
     if n > dets.shape[1]:
-        dets, _, _, cnt = hip.postprocess_detections(rois5, None, cls, dl, sf, sz, weights=bbox_reg_weights, max_out=n)
+        dets, _, _, cnt = hip.postprocess_detections(rois5, None, cls, dl, sf, sz, weights=bbox_reg_weights, max_out=n,
+                                                     scores_are_logits=class_scores_are_logits)
     return _split_by_class(dets[0].cpu().numpy(), n, n_cls)
 
 
@@ -176,3 +184,72 @@ def segm_results(cls_boxes, masks, ref_boxes, im_h, im_w, num_classes=81, M=14, 
         cls_segms[int(cls_of[d])].append({'size': [int(im_h), int(im_w)],
                                           'counts': sbuf[d, :slen[d]].tobytes().decode('ascii')})
     return cls_segms
+
+
+def assemble_results(dets, det_count, im_sizes=None, rle_str=None, rle_len=None, num_classes=81, all_boxes=None,
+                     all_segms=None, first_image=0):
+    """all_boxes / all_segms (result_utils.py:32-60) from the fixed-shape outputs of the batched path.
+
+      dets [N, max_out, 6] = (x1,y1,x2,y2,score,class) class-major per image, det_count [N]   (dtc_postprocess_detections,
+      or detectorch_amd.dist.ResultGatherer.finish() reshaped to [images, ...])
+      rle_str uint8 [N, max_out, stride] + rle_len int32 [N, max_out] (dtc_mask_rle) and im_sizes [N,2] = (h, w): optional
+
+    all_boxes[cls][image] = [k,5] array (x1,y1,x2,y2,score); all_segms[cls][image] = list of COCO RLE dicts in 1:1
+    correspondence -- exactly what `extend_results(i, all_boxes, cls_boxes_i)` / `extend_results(i, all_segms, cls_segms_i)`
+    leave behind image by image in the reference's eval loop.  Pass all_boxes / all_segms / first_image to fill a slice of
+    existing lists (e.g. the shard of one rank)."""
+    dets, det_count = to_np(dets), to_np(det_count).reshape(-1)
+    N, max_out = dets.shape[0], dets.shape[1]
+    if all_boxes is None:
+        all_boxes, all_segms, _ = empty_results(num_classes, first_image + N)
+    want_segms = rle_str is not None
+    if want_segms:
+        rle_str, rle_len = to_np(rle_str), to_np(rle_len).reshape(N, -1)
+        im_sizes = to_np(im_sizes).reshape(N, -1)
+    for i in range(N):
+        n = min(int(det_count[i]), max_out)
+        d = dets[i, :n]
+        cls = d[:, 5].astype(np.int64)
+        for j in range(1, num_classes):
+            sel = np.flatnonzero(cls == j)
+            all_boxes[j][first_image + i] = np.ascontiguousarray(d[sel, :5])
+            if want_segms:
+                h, w = int(im_sizes[i, 0]), int(im_sizes[i, 1])
+                segs = []
+                for k in sel:
+                    if rle_len[i, k] < 0:
+                        raise RuntimeError("device RLE buffer too small for image %d detection %d" % (first_image + i, k))
+                    segs.append({'size': [h, w], 'counts': rle_str[i, k, :rle_len[i, k]].tobytes().decode('ascii')})
+                all_segms[j][first_image + i] = segs
+    return all_boxes, all_segms
+
+
+def coco_bbox_results(all_boxes, image_ids, class_to_cat_id):
+    """The records _write_coco_bbox_results_file dumps (json_dataset_evaluator.py:149-190): xywh boxes, one dict per detection.
+    class_to_cat_id[j] = COCO category id of class index j (index 0 = background, ignored)."""
+    res = []
+    for j in range(1, len(all_boxes)):
+        for i, image_id in enumerate(image_ids):
+            d = all_boxes[j][i]
+            if isinstance(d, list) and len(d) == 0:
+                continue
+            d = np.asarray(d, dtype=np.float64)
+            xywh = box_utils.xyxy_to_xywh(d[:, 0:4])
+            res.extend({'image_id': image_id, 'category_id': class_to_cat_id[j],
+                        'bbox': [xywh[k, 0], xywh[k, 1], xywh[k, 2], xywh[k, 3]], 'score': d[k, -1]} for k in range(d.shape[0]))
+    return res
+
+
+def coco_segm_results(all_boxes, all_segms, image_ids, class_to_cat_id):
+    """The records _write_coco_segms_results_file dumps (json_dataset_evaluator.py:67-113)."""
+    res = []
+    for j in range(1, len(all_boxes)):
+        for i, image_id in enumerate(image_ids):
+            d, rles = all_boxes[j][i], all_segms[j][i]
+            if isinstance(d, list) and len(d) == 0:
+                continue
+            d = np.asarray(d, dtype=np.float64)
+            assert len(rles) == d.shape[0]
+            res.extend({'image_id': image_id, 'category_id': class_to_cat_id[j], 'segmentation': rles[k], 'score': d[k, -1]}
+                       for k in range(d.shape[0]))
+    return res

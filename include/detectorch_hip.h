@@ -192,6 +192,18 @@ int dtc_postprocess_detections(const float* rois5, const int32_t* n_rois, const 
                                void* workspace, size_t workspace_bytes, float* dets, int32_t* det_roi,
                                float* det_rois_scaled, int32_t* det_count, int max_out, dtc_stream_t stream);
 
+/* Same with the box head's softmax folded in (lib/model/detector.py:281 F.softmax(cls_score) -> result_utils.py:76-94):
+ * cls_logits [B,R,n_cls] is the raw output of the cls_score layer.  One wave per roi reduces (max, sum exp) -- 16 bytes per
+ * roi in the workspace -- and the probability of a (roi, class) is formed where the class column is scanned:
+ * float(exp(double(l) - max) / sum), rounded once (rel 1e-6 of torch's float32 softmax).  The [R,n_cls] probability
+ * map is never written.  Everything else as dtc_postprocess_detections; same workspace size. */
+int dtc_postprocess_detections_logits(const float* rois5, const int32_t* n_rois, const float* cls_logits,
+                                      const float* bbox_pred, const float* scaling_factor, const float* im_size, int batch,
+                                      int max_rois, int n_cls, float wx, float wy, float ww, float wh, float score_thresh,
+                                      float nms_thresh, int max_det, void* workspace, size_t workspace_bytes, float* dets,
+                                      int32_t* det_roi, float* det_rois_scaled, int32_t* det_count, int max_out,
+                                      dtc_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * A9  Mask resize + binarise (+ paste geometry)
  * --------------------------------------------------------------------------------------------------------------- */

@@ -131,6 +131,23 @@ def rpn_sigmoid(logits):
     return (1.0 / (1.0 + np.exp(-x))).astype(np.float32)
 
 
+def softmax_rows(logits):
+    """F.softmax(cls_score) of lib/model/detector.py:281 restated as the correctly-rounded value: exp and the sum in float64,
+    one rounding to float32 at the end.  The sum is taken in the order the HIP kernel uses (element j into slot j % 64 in
+    increasing j, then a 64 -> 1 halving tree) so that the two agree bit for bit; torch's own float32 softmax agrees to rel 1e-6
+    (tests/test_oracle_golden.py)."""
+    l = np.asarray(logits, np.float32)
+    m = l.max(axis=-1, keepdims=True).astype(np.float64)
+    e = np.exp(l.astype(np.float64) - m)
+    n = l.shape[-1]
+    s = np.zeros(l.shape[:-1] + (64,), np.float64)
+    for j in range(n):
+        s[..., j % 64] += e[..., j]
+    for off in (32, 16, 8, 4, 2, 1):
+        s = s[..., :off] + s[..., off:2 * off]
+    return (e / s).astype(np.float32)
+
+
 def generate_proposals(scores, deltas, anchors, feat_stride, im_h, im_w, pre_nms_top_n, post_nms_top_n, nms_thresh,
                        min_size_scaled=0.0, return_pre_nms=False):
     """scores [A,H,W], deltas [4A,H,W] -> (boxes [k,4], scores [k])."""

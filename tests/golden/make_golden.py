@@ -56,11 +56,33 @@ def bbox_vote(ns):
     save("bbox_vote", **arrs)
 
 
+def postprocess_logits(ns):
+    """the box head's softmax + postprocess_output.  Logits -> torch CPU F.softmax (what lib/model/detector.py:281
+    runs) -> the reference's postprocess_output, imported in place.  The fused HIP path gets the LOGITS."""
+    import torch.nn.functional as F
+    rs = synth.rng(7, 0)
+    R = 300
+    rois = synth.make_rois(rs, R)
+    logits = (rs.standard_normal((R, 81)) * 3.0).astype(np.float32)
+    logits[:, 0] -= 1.0
+    deltas = (rs.standard_normal((R, 324)) * 0.1).astype(np.float32)
+    im_size = np.array([500.0, 833.0, 3.0], np.float32)
+    sf = np.float32(1.6)
+    prob = F.softmax(torch.from_numpy(logits), dim=1)
+    scores_final, boxes_final, cls_boxes = ns.result_utils.postprocess_output(
+        torch.from_numpy(rois), float(sf), torch.from_numpy(im_size), prob, torch.from_numpy(deltas))
+    cls_id = np.concatenate([np.full(len(cls_boxes[j]), j, np.int32) for j in range(1, 81)])
+    save("postprocess_logits", rois=rois, logits=logits, deltas=deltas, im_size=im_size, sf=np.array([sf], np.float32),
+         prob_torch=prob.numpy(), scores_final=scores_final, boxes_final=boxes_final, cls_id=cls_id)
+
+
 def main():
     ns = rh.load_reference()
     torch.manual_seed(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bbox_vote":     # add one fixture without rewriting the others
         return bbox_vote(ns)
+    if len(sys.argv) > 1 and sys.argv[1] == "postprocess_logits":
+        return postprocess_logits(ns)
 
     # ---- A2 anchors (generate_anchors.py:54) -------------------------------------------------------------------
     arrs = {}
@@ -198,6 +220,7 @@ def main():
         arrs["exp_int_M%d" % M] = ns.boxes.expand_boxes(ref_boxes, (M + 2.0) / M).astype(np.int32)
     save("mask_geometry", **arrs)
     bbox_vote(ns)
+    postprocess_logits(ns)
 
 
 if __name__ == "__main__":

@@ -61,3 +61,69 @@ def test_faster_rcnn_c4_flow():
     cls_score, bbox_pred, rois, feats = model(image, scaling_factor=1.0)
     assert rois.shape[1] == 4 and cls_score.shape[0] == rois.shape[0] and bbox_pred.shape[1] == 324
     assert tuple(feats.shape) == (1, 1024, 16, 20)
+
+
+def _boost(model, k=60.0):
+    # random weights give ~uniform class scores (1/81 < the 0.05 detection threshold): sharpen the classifier so that
+    # detections exist and the NMS / top-100 / mask branches run
+    model.classif_head.weight.data *= k
+    return model
+
+
+def test_forward_batched_equals_reference_shaped_forward():
+    """detector.forward_batched (backbone(B) -> FpnRegionPath stages -> heads -> detections -> mask branch, no host round
+    trip) against the reference-shaped batch-1 calls: forward() + postprocess_output + add_multilevel_rois_for_test +
+    mask_head + segm_results (eval_mask_FPN.ipynb cells 4, 6)."""
+    from detectorch_amd.model.detector import detector
+    from detectorch_amd.utils import result_utils
+    from detectorch_amd.utils.multilevel_rois import add_multilevel_rois_for_test
+    model = _boost(_fpn_model())
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    image = torch.randn(1, 3, 320, 448, generator=g, device="cuda")
+    sf, im_size = torch.tensor([1.6], device="cuda"), torch.tensor([[200.0, 280.0]], device="cuda")
+    path = model.forward_batched(image, sf, im_size)
+    torch.cuda.synchronize()
+    cls_b, bbox_b, rois_b, feats_b = detector.per_image(path, 0)
+    cls_score, bbox_pred, rois, feats = model(image, scaling_factor=sf)
+    assert torch.equal(rois, rois_b)
+    assert torch.allclose(bbox_pred, bbox_b, rtol=1e-4, atol=1e-5) and torch.allclose(cls_score, cls_b, rtol=1e-4, atol=1e-6)
+    scores_final, boxes_final, boxes_per_class = result_utils.postprocess_output(rois, sf, im_size[0], cls_score, bbox_pred)
+    D = boxes_final.shape[0]
+    assert D > 0 and D == min(int(path.det_count[0]), path.max_out)
+    dets = path.dets[0, :D].cpu().numpy()
+    assert np.array_equal(dets[:, 5].astype(np.int64), np.concatenate([np.full(len(boxes_per_class[j]), j) for j in range(1, 81)]))
+    assert np.allclose(dets[:, 4], scores_final, rtol=1e-4, atol=1e-6) and np.allclose(dets[:, :4], boxes_final, atol=1e-2)
+    # mask branch: the reference-shaped calls on the same detections
+    blobs = add_multilevel_rois_for_test({'rois': boxes_final * 1.6}, 'rois')
+    per_level = [torch.from_numpy(blobs[k]).cuda() if len(blobs[k]) > 0 else None for k in ['rois_fpn2', 'rois_fpn3', 'rois_fpn4', 'rois_fpn5']]
+    masks = model.mask_head(feats, per_level, torch.from_numpy(blobs['rois_idx_restore_int32']).cuda().long())
+    assert torch.allclose(masks, path.masks[:D], rtol=1e-3, atol=1e-4)
+    segms = result_utils.segm_results(boxes_per_class, masks, boxes_final, 200, 280, M=28)
+    _, got_segms = result_utils.assemble_results(path.dets, path.det_count, path.im_size, path.rle_str, path.rle_str_len)
+    n_same = sum(a == b for j in range(1, 81) for a, b in zip(segms[j], got_segms[j][0]))
+    assert sum(len(s) for s in segms) == D and n_same >= D - 2          # identical up to a pixel at the 0.5 contour
+
+
+def test_forward_batched_batch2_and_bf16_head():
+    """B = 2 runs both images at once (image 0 == its batch-1 result up to conv-batch rounding: same proposals); the bf16 head
+    option (RoIAlign writes bf16, fc6/fc7 as bf16 MFMA GEMMs) stays within bf16 rounding of the fp32 head."""
+    from detectorch_amd.model.detector import detector
+    model = _boost(_fpn_model())
+    g = torch.Generator(device="cuda"); g.manual_seed(6)
+    images = torch.randn(2, 3, 320, 448, generator=g, device="cuda")
+    sf, im_size = torch.tensor([1.6, 1.6], device="cuda"), torch.tensor([[200.0, 280.0], [200.0, 280.0]], device="cuda")
+    p2 = model.forward_batched(images, sf, im_size)
+    n2 = p2.n_rois.tolist()
+    rois2 = p2.rois5[0, :n2[0], 1:].clone()
+    d2 = p2.det_count.tolist()
+    p1 = model.forward_batched(images[:1], sf[:1], im_size[:1])
+    assert n2[0] == int(p1.n_rois[0]) and min(d2) > 0
+    assert torch.allclose(rois2, p1.rois5[0, :n2[0], 1:], atol=1e-2)
+    assert float(p2.rois5[1, :, 0].min()) == 1.0                       # image index carried in column 0
+    ref_logits = p1.cls_logits_out.clone()
+    model.head_dtype = torch.bfloat16
+    model._paths.clear()
+    pb = model.forward_batched(images[:1], sf[:1], im_size[:1])
+    assert pb.box_feats.dtype == torch.bfloat16
+    err = (pb.cls_logits_out - ref_logits).abs().max() / ref_logits.abs().max()
+    assert float(err) < 5e-2

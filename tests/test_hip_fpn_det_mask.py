@@ -332,3 +332,80 @@ def test_device_rle_full_size_property(hip, oracle):
         dec = np.repeat(np.arange(n) % 2, runs).astype(np.uint8).reshape(im_w, im_h).T
         assert np.array_equal(dec, fr)
         assert out["str"][d, :out["str_len"][d]].tobytes().decode("ascii") == oracle.rle_encode(fr)[1]
+
+
+# ---------------------------------------------------------------- 8f-2: softmax folded into the detection kernel ------
+def test_postprocess_from_logits_golden_and_oracle(hip, oracle):
+    """dtc_postprocess_detections_logits: class LOGITS in, the F.softmax of lib/model/detector.py:281 formed inside the kernel.
+    (1) == the unfused kernel fed oracle.softmax_rows(logits), bit for bit; (2) == the oracle chain; (3) vs the golden the
+    reference's own postprocess_output produced from torch's float32 softmax: same detections, scores to 2e-7, boxes to
+    1e-4 / 1 ulp."""
+    from detectorch_amd.utils import result_utils
+    g = golden("postprocess_logits")
+    R = g["rois"].shape[0]
+    rois5 = np.hstack([np.zeros((R, 1), np.float32), g["rois"]])[None]
+    args = (cu(rois5), None, None, cu(g["deltas"][None]), cu(g["sf"]), cu(g["im_size"][:2][None]))
+    fused = hip.postprocess_detections(args[0], None, cu(g["logits"][None]), *args[3:], scores_are_logits=True)
+    prob = oracle.softmax_rows(g["logits"])
+    plain = hip.postprocess_detections(args[0], None, cu(prob[None]), *args[3:])
+    for a, b in zip(fused, plain):
+        assert torch.equal(a, b)
+    n = int(fused[3][0])
+    ref, ref_roi = oracle.postprocess_detections(g["rois"], g["sf"][0], g["im_size"], prob, g["deltas"])
+    assert n == ref.shape[0] and np.array_equal(fused[0][0, :n].cpu().numpy(), ref)
+    assert np.array_equal(fused[1][0, :n].cpu().numpy(), ref_roi)
+    # reference-shaped module call, against the reference-generated golden
+    sc, bx, cls_boxes = result_utils.postprocess_output(g["rois"], g["sf"], g["im_size"], g["logits"], g["deltas"],
+                                                        class_scores_are_logits=True)
+    assert np.array_equal(np.concatenate([np.full(len(cls_boxes[j]), j, np.int32) for j in range(1, 81)]), g["cls_id"])
+    assert np.allclose(sc, g["scores_final"], rtol=0, atol=2e-7) and ulp_close(bx, g["boxes_final"])
+    # batched, ragged roi counts, > 128 classes
+    rs = synth.rng(7, 3)
+    B, R2, C2 = 3, 200, 150
+    lg = (rs.standard_normal((B, R2, C2)) * 4).astype(np.float32)
+    dl = (rs.standard_normal((B, R2, 4 * C2)) * 0.1).astype(np.float32)
+    r5 = np.stack([np.hstack([np.full((R2, 1), b, np.float32), synth.make_rois(rs, R2)]) for b in range(B)])
+    nr = np.array([200, 37, 0], np.int32)
+    sf, im = np.array([1.6, 1.0, 2.0], np.float32), np.array([[500, 833], [800, 1333], [400, 600]], np.float32)
+    out = hip.postprocess_detections(cu(r5), cu(nr), cu(lg), cu(dl), cu(sf), cu(im), scores_are_logits=True)
+    for b in range(B):
+        ref, _ = oracle.postprocess_detections(r5[b, :nr[b], 1:], sf[b], im[b], oracle.softmax_rows(lg[b, :nr[b]]), dl[b, :nr[b]])
+        k = int(out[3][b])
+        assert k == ref.shape[0] and np.array_equal(out[0][b, :min(k, 128)].cpu().numpy(), ref[:128])
+
+
+# ---------------------------------------------------------------- 8f-4: all_boxes / all_segms assembly -----------------
+def test_assemble_results_from_batched_path_equals_per_image_flow(hip, oracle):
+    """all_boxes / all_segms built in one go from the fixed-shape device outputs of the batched path (dets + device RLE
+    strings) == the reference's per-image flow: postprocess_output -> segm_results -> extend_results (result_utils.py:32-60,
+    76-94, 170-228; eval_mask_FPN.ipynb cell 6)."""
+    from detectorch_amd.pipeline import FpnRegionPath, synthetic_batch
+    from detectorch_amd.utils import result_utils
+    dev = torch.device("cuda", 0)
+    B, C = 2, 8
+    path = FpnRegionPath(B, dev, channels=C, with_rle=True)
+    inputs = synthetic_batch(B, dev, seed=3200, channels=C)
+    path.bind(*inputs)
+    path.step(use_graph=True)
+    path.step(use_graph=True)
+    torch.cuda.synchronize()
+    assert int(path.rle_str_len.min()) >= 0
+    boxes, segms = result_utils.assemble_results(path.dets, path.det_count, path.im_size, path.rle_str, path.rle_str_len)
+    rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, sf, im_size = inputs
+    exp_boxes, exp_segms, _ = result_utils.empty_results(81, B)
+    for b in range(B):
+        n = int(path.n_rois[b])
+        sc, bx, cls_boxes = result_utils.postprocess_output(path.rois5[b, :n, 1:], sf[b:b + 1], im_size[b], cls_score[b, :n],
+                                                            bbox_pred[b, :n])
+        D = bx.shape[0]
+        assert D == min(int(path.det_count[b]), path.max_out)
+        cls_segms = result_utils.segm_results(cls_boxes, masks[b * path.max_out:b * path.max_out + D], bx, int(im_size[b, 0]),
+                                              int(im_size[b, 1]), M=28)
+        result_utils.extend_results(b, exp_boxes, cls_boxes)
+        result_utils.extend_results(b, exp_segms, cls_segms)
+    for j in range(1, 81):
+        for b in range(B):
+            assert np.array_equal(boxes[j][b], exp_boxes[j][b]), (j, b)
+            assert segms[j][b] == exp_segms[j][b], (j, b)
+    recs = result_utils.coco_segm_results(boxes, segms, [11, 12], {j: j + 100 for j in range(81)})
+    assert len(recs) == sum(min(int(c), path.max_out) for c in path.det_count.tolist())

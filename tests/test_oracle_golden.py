@@ -165,3 +165,26 @@ def test_bbox_overlaps_and_voting_golden(oracle):
     assert np.array_equal(oracle.bbox_overlaps(g["top_dets"][:, :4], g["all_dets"][:, :4]), g["overlaps_top"])
     assert np.array_equal(oracle.box_voting(g["top_dets"], g["all_dets"], 0.6), g["vote_ID_b10"])
     assert (g["overlaps_top"] >= 0.6).sum(1).max() > 8          # the pairwise-sum branch (>= 8 voters) is exercised
+
+
+def test_softmax_rows_vs_torch_and_reference_golden(oracle):
+    """oracle.softmax_rows (float64 exp + fixed-order sum, rounded once) against torch CPU F.softmax -- the
+    operation lib/model/detector.py:281 runs -- within rel 1e-6, and the chain softmax_rows -> postprocess_detections against
+    the golden produced by the reference's own postprocess_output on torch's softmax (tests/golden/make_golden.py)."""
+    import torch
+    import torch.nn.functional as F
+    g = golden("postprocess_logits")
+    p = oracle.softmax_rows(g["logits"])
+    pt = F.softmax(torch.from_numpy(g["logits"]), dim=1).numpy()
+    assert np.array_equal(pt, g["prob_torch"])
+    assert np.allclose(p, pt, rtol=1e-6, atol=1e-12)       # torch evaluates exp / sum / divide in float32: a few ulp on small entries
+    assert np.allclose(p.sum(1), 1.0, atol=1e-6)
+    rs = np.random.RandomState(0)
+    big = (rs.standard_normal((50, 200)) * 30).astype(np.float32)            # > 128 classes, saturating logits
+    pb, ptb = oracle.softmax_rows(big), F.softmax(torch.from_numpy(big), dim=1).numpy()
+    assert np.allclose(pb, ptb, rtol=2e-5, atol=1e-37)      # |x - max| ~ 100: the float32 subtraction alone costs rel 4e-6
+    dets, _ = oracle.postprocess_detections(g["rois"], g["sf"][0], g["im_size"], p, g["deltas"])
+    assert dets.shape[0] == g["scores_final"].shape[0]
+    assert np.array_equal(dets[:, 5].astype(np.int32), g["cls_id"])
+    assert np.allclose(dets[:, 4], g["scores_final"], rtol=0, atol=2e-7)
+    assert ulp_close(dets[:, :4], g["boxes_final"])
