@@ -15,19 +15,19 @@
 //   * element strides instead of a fixed NCHW layout, fp32 / fp16 / bf16 features, fp32 accumulation.
 //
 // Kernels in this file (all produce bit-identical results; tests/test_hip_roi_align.py runs every one against the oracle):
-//   roi_align_fwd_lds      DEFAULT for NCHW (and for channels_last with many taps per pixel): window staged in LDS through a
-//                          register prefetch pipeline; stagers StagerNCHW (dword per lane), StagerNCHW2 (pixel pairs, the
-//                          default for fp16/bf16), StagerNHWC, and the opt-in StagerRow4
-//   roi_align_fwd_nhwc     DEFAULT for channels_last features with few taps per pixel: taps gathered straight from L1/L2
-//   roi_align_fwd_general  per-output gather; oversize pooled sizes, and the reference implementation of the arithmetic
-//   roi_align_fwd_ws / roi_align_fwd_dma   measured-slower experiments (wave specialisation, LDS-DMA staging), opt-in
-// Environment knobs, read at every dispatch (A/B measurements and the variant tests; DESIGN.md section 3.1 has the numbers):
-//   DTC_ROIALIGN_GENERAL, DTC_ROIALIGN_NO_NHWC_DIRECT, DTC_ROIALIGN_WS, DTC_ROIALIGN_DMA   kernel selection
-//   DTC_ROIALIGN_LDS_KB (52)  DTC_RA_CHBLOCK (128)                                          workgroup shape
-//   DTC_RA_NO_XCD  DTC_RA_NO_CTS64  DTC_RA_NO_PAIRS                                         turn a default optimisation off
-//   DTC_RA_ROW4  DTC_RA_QUAD  DTC_RA_ROWSLOTS  DTC_RA_PAIRS32                                turn a measured-neutral/slower one on
+//   roi_align_fwd_lds      RoI-stationary: one workgroup per (RoI, channel block), window staged in LDS through a register
+//                          prefetch pipeline; stagers StagerNCHW (dword per lane), StagerNCHW2 (pixel pairs: 2-byte features),
+//                          StagerNHWC.  The path for adaptive sampling (sampling_ratio <= 0: the C4 configurations), for
+//                          sampling ratios other than 2, and the A/B partner of the cluster-stationary kernel.
+//   roi_align_fwd_nhwc     channels_last features with few taps per pixel: taps gathered straight from L1/L2
+//   roi_align_fwd_general  per-output gather; oversize pooled sizes, and the plain statement of the arithmetic
+// The default for the FPN heads (NCHW features, sampling_ratio 2) is the cluster-stationary kernel in roi_align_tile.hip.
+// Knobs (resolved once per process): see RoiAlignConfig below.  Variants measured slower in round 1 (wave-specialised
+// loader/compute waves, LDS-DMA staging, 16-byte row pieces, row-slot chunking, quad-aligned windows) were removed in
+// round 2; DESIGN.md section 3.1 keeps their numbers.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "roi_align_common.h"
@@ -156,34 +156,6 @@ struct StagerNCHW {
       lbase[k] = lp * ctp + cl;
       pix += 64; px += r64; py += q64;
       if (px >= ww) { px -= ww; py++; }
-    }
-  }
-  // Row-slot enumeration: chunk k of wave wv is the 16-pixel segment (row, seg) = divmod(wv + 4k, nseg) of the window, so a
-  // row piece is consumed by ONE wave-instruction (x 4 channel planes).  With the linear pixel order of init() a row piece is
-  // split between two chunks that belong to different waves; the 32 KB L1 (256 lines, ~1200 lines in flight per CU) has
-  // evicted the line by the time the second wave asks for it: measured 6.5 K line fills per RoI against 3.1 K distinct lines.
-  __device__ __forceinline__ void init_rows(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int npix, int cts) {
-    const int tid = threadIdx.x;
-    const int pl = tid & 15, wv = tid >> 6;
-    cl = (tid >> 4) & 3;
-    stride_c = L.stride_c;
-    const int ctp = cts + kLdsPad;
-    const int nseg = (ww + 15) >> 4;
-    const int nslots = wh * nseg;
-    nk = ceil_div(nslots, kRoiAlignThreads / 64);
-    const float rinv = 1.0f / (float)nseg;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      const int sl = wv + (kRoiAlignThreads / 64) * k;
-      const int slc = min(sl, nslots - 1);
-      const int row = (int)(((float)slc + 0.5f) * rinv);          // exact for small integers
-      const int seg = slc - row * nseg;
-      const int px = seg * 16 + pl;
-      const bool ok = sl < nslots && px < ww;
-      const int lx = min(px, ww - 1);                             // lanes past the row end re-read its last pixel (same line)
-      voff[k] = (uint32_t)(((int64_t)(y0 + row) * L.stride_h + (int64_t)(x0 + lx) * L.stride_w + (int64_t)cl * L.stride_c) *
-                           (int64_t)sizeof(TIn));
-      lbase[k] = (ok ? row * ww + px : npix) * ctp + cl;          // ... and write to the dummy slot
     }
   }
   // full sub-tile (all cts channels valid)
@@ -358,71 +330,6 @@ struct StagerNHWC {
   }
 };
 
-// NCHW, 16-byte row pieces (the default for the reference's layout when rows are 16-byte aligned: stride_w == 1 and
-// W, H*W multiples of 4).  The window is widened to 4-pixel boundaries [xa, xa + 4*ng) and a lane loads FOUR consecutive
-// pixels of one channel row with ONE global_load_dwordx4 (fp16: dwordx2) -- 3.5x fewer vector-memory instructions and
-// L1 accesses than one dword per lane for the same lines (PMC: the dword stager spends ~46 % of the TCP cycles stalled on
-// pending requests).  thread -> fixed channel (tid % cts) x positions (row, 4-pixel group) p0 + k*(256/cts): a wave covers
-// cts channels x 64/cts positions, so the four transposing ds_write_b32 of a piece (pixel stride ctp: 16*(m&1) + channel
-// mod 32 banks) are 2-way = free for cts 32/16.  Padding columns hold real neighbouring pixels; the axis tables are made
-// relative to xa, so the compute phase is unchanged.  At most K = 8 pieces (32 registers) per thread and sub-tile.
-template <typename TIn>
-struct StagerRow4 {
-  static constexpr int K = 8;
-  float4 v[K];
-  uint32_t voff[K];
-  int32_t lbase[K];
-  int nk, ch, ctp;
-  uint32_t okmask;
-  static __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-  static __device__ __forceinline__ float4 load4(const __half* p) {
-    const uint2 r = *reinterpret_cast<const uint2*>(p);
-    const __half2 a = *reinterpret_cast<const __half2*>(&r.x), b = *reinterpret_cast<const __half2*>(&r.y);
-    return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
-  }
-  static __device__ __forceinline__ float4 load4(const bf16_t* p) { return bf16x4_to_f32(*reinterpret_cast<const uint2*>(p)); }
-  __device__ __forceinline__ void init(const dtc_feat_level& L, int y0, int xa, int ng, int wh, int cts) {
-    const int tid = threadIdx.x;
-    ch = tid & (cts - 1);
-    const int sh = 31 - __clz(cts);                 // cts is a power of two
-    const int p0 = tid >> sh, np = kRoiAlignThreads >> sh;
-    const int npg = wh * ng, wwa = 4 * ng;
-    ctp = cts + kLdsPad;
-    nk = ceil_div(npg, np);
-    const float rinv = 1.0f / (float)ng;
-    okmask = 0;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      const int pos = p0 + np * k;
-      const bool ok = pos < npg;
-      const int pp = ok ? pos : npg - 1;
-      const int row = (int)(((float)pp + 0.5f) * rinv);   // exact for pp < 2^12 (distance to an integer boundary >= 0.5/ng)
-      const int g = pp - row * ng;
-      okmask |= ok ? (1u << k) : 0u;
-      voff[k] = (uint32_t)(((int64_t)(y0 + row) * L.stride_h + (int64_t)(xa + 4 * g) + (int64_t)ch * L.stride_c) *
-                           (int64_t)sizeof(TIn));
-      lbase[k] = (row * wwa + 4 * g) * ctp + ch;
-    }
-  }
-  __device__ __forceinline__ void issue(const TIn* cbase, int cts, int nvalid) {
-    const char* cb = reinterpret_cast<const char*>(cbase);
-    if (ch < nvalid) {      // channel tail: planes past the end are not read; their LDS columns are never stored
-#pragma unroll
-      for (int k = 0; k < K; k++)
-        if (k < nk && ((okmask >> k) & 1u)) v[k] = load4(reinterpret_cast<const TIn*>(cb + voff[k]));
-    }
-  }
-  __device__ __forceinline__ void commit(float* win, int cts) {
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      if (k < nk && ((okmask >> k) & 1u)) {
-        float* d = win + lbase[k];
-        d[0] = v[k].x; d[ctp] = v[k].y; d[2 * ctp] = v[k].z; d[3 * ctp] = v[k].w;
-      }
-    }
-  }
-};
-
 // axis-table entry of the LDS kernel: window-relative, premultiplied
 struct LdsAxis { int lo, hi; float l, h; };   // y: (row - y0) * ww * ctp ; x: (col - x0) * ctp   [LDS words]
 
@@ -563,35 +470,8 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   const int tabf = ((ny + nx) * 4 + 15) & ~15;
   const int avail = lds_floats - tabf;
   int cts = 0;
-  // 16-byte row pieces (StagerRow4) when every row of this level starts on a 4-element boundary
-  bool row4 = p.row4 && L.stride_w == 1 && ((L.width | L.stride_h | L.stride_c | L.stride_n) & 3) == 0 &&
-              (reinterpret_cast<uintptr_t>(L.data) & (4 * sizeof(TIn) - 1)) == 0;
-  int xa = x0, ng = 0;
-  if (row4) {
-    xa = x0 & ~3;
-    ng = (x1 >> 2) - (x0 >> 2) + 1;
-    const int npg = wh * ng, npa = npg * 4;
-#pragma unroll
-    for (int c = 32; c >= 8; c >>= 1)      // K = 8 pieces per thread: positions <= 8 * 256 / cts
-      if (cts == 0 && npg * c <= 8 * kRoiAlignThreads &&
-          (long long)(npa + 1) * (c + kLdsPad) + (long long)c * bins <= avail) cts = c;
-    if (cts != 0) { x0 = xa; ww = 4 * ng; npix = npa; } else row4 = false;
-  }
-  // Quad alignment (measured with tools/micro/tcp_access_patterns.hip): the texture addresser coalesces a wave's dword
-  // loads per QUAD of lanes -- four lanes reading four consecutive dwords of one 16-byte-aligned unit are one L1 access and
-  // neighbouring quads merge into 64-byte accesses (6-10 accesses per wave-instruction); a quad that straddles a row break
-  // or starts off a 16-byte boundary degrades the whole instruction to one access per lane (~40).  With an arbitrary
-  // window (x0, ww ~ 9) nearly every quad straddles.  So the staged window is widened to 4-pixel boundaries whenever the
-  // level's rows are 4-element aligned: chunks of 16 lanes then always hold whole aligned quads of one row.  The extra
-  // columns are real neighbouring pixels (never sampled); the axis tables are relative to the widened origin.
-  if (!row4 && p.quad_align && L.stride_w == 1 && ((L.width | L.stride_h | L.stride_c | L.stride_n) & 3) == 0 &&
-      (reinterpret_cast<uintptr_t>(L.data) & (4 * sizeof(TIn) - 1)) == 0) {
-    x0 = x0 & ~3;
-    ww = ((x1 >> 2) - (x0 >> 2) + 1) * 4;
-    npix = wh * ww;
-  }
   // pixel-pair loads (StagerNCHW2) when rows start on even elements: dword pairs for fp16/bf16, dwordx2 pairs for fp32
-  const bool pairs = p.pair_loads && (sizeof(TIn) == 2 || p.pair_loads > 1) && !row4 && L.stride_c != 1 && L.stride_w == 1 &&
+  const bool pairs = p.pair_loads && (sizeof(TIn) == 2 || p.pair_loads > 1) && L.stride_c != 1 && L.stride_w == 1 &&
                      ((L.width | L.stride_h | L.stride_c | L.stride_n) & 1) == 0 &&
                      (reinterpret_cast<uintptr_t>(L.data) & (2 * sizeof(TIn) - 1)) == 0;
   const int pair_budget = sizeof(TIn) == 2 ? 8192 : 4096;   // pairs x channels a workgroup holds in 32 registers per thread
@@ -599,14 +479,6 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
     x0 = x0 & ~1;
     ww = ((x1 >> 1) - (x0 >> 1) + 1) * 2;
     npix = wh * ww;
-  }
-  bool row_slots = false;
-  if (!row4 && !pairs && p.row_slots && L.stride_c != 1) {
-    const int nslots = wh * ((ww + 15) >> 4);
-#pragma unroll
-    for (int c = 32; c >= 8; c >>= 1)      // K = 128 / c chunks per thread, 4 slots per chunk round
-      if (cts == 0 && nslots * c <= 512 && (long long)(npix + 1) * (c + kLdsPad) + (long long)c * bins <= avail) cts = c;
-    row_slots = cts != 0;
   }
   // one dword per lane; the per-thread share of the window must fit the 32 prefetch registers (npix * cts <= 8192)
   if (p.cts64 && pairs && cts == 0 && nc >= 64 && (npix / 2) * 64 <= pair_budget &&
@@ -652,10 +524,7 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   G.cts = cts; G.bins = bins; G.gh = gh; G.gw = gw; G.pooled_w = p.pooled_w; G.nc = nc; G.count = count;
   G.inv_count = hd.inv_count;
   const TIn* cbase = fbase + (int64_t)c0 * L.stride_c;
-  if (row4) {
-    StagerRow4<TIn> st; st.init(L, y0, xa, ng, wh, cts);
-    run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out);
-  } else if (pairs) {
+  if (pairs) {
     const int nkp = ceil_div(ceil_div(npix / 2, 16), kRoiAlignThreads / 64);
 #define DTC_RUN2(KK, GG) { StagerNCHW2<TIn, KK, GG> st; st.init(L, y0, x0, ww, wh, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
     if constexpr (sizeof(TIn) == 2) {
@@ -674,13 +543,8 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
     StagerNHWC<TIn> st; st.init(L, y0, x0, ww, wh, npix, cts);
     run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out);
   } else {
-    const int nk = row_slots ? ceil_div(wh * ((ww + 15) >> 4), kRoiAlignThreads / 64)
-                             : ceil_div(ceil_div(npix, 16), kRoiAlignThreads / 64);
-    if (row_slots) {
-      if (nk <= 4) { StagerNCHW<TIn, 4, 8> st; st.init_rows(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
-      else if (nk <= 8) { StagerNCHW<TIn, 8, 4> st; st.init_rows(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
-      else { StagerNCHW<TIn, 16, 2> st; st.init_rows(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
-    } else if (cts == 64) { StagerNCHW<TIn, 2, 16> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
+    const int nk = ceil_div(ceil_div(npix, 16), kRoiAlignThreads / 64);
+    if (cts == 64) { StagerNCHW<TIn, 2, 16> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
     else if (nk <= 4) { StagerNCHW<TIn, 4, 8> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
     else if (nk <= 8) { StagerNCHW<TIn, 8, 4> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
     else { StagerNCHW<TIn, 16, 2> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
@@ -825,527 +689,60 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
   }
 }
 
+// ---- host side ------------------------------------------------------------------------------------------------------------
+// Development / A-B knobs, resolved ONCE per process (thread-safe static initialisation) -- not per dispatch:
+//   DTC_ROIALIGN_TILE=0          use the RoI-stationary kernel of this file instead of the cluster-stationary one (roi_align_tile.hip)
+//   DTC_ROIALIGN_GENERAL=1       force the per-output gather kernel (the plain statement of the arithmetic)
+//   DTC_ROIALIGN_NO_NHWC_DIRECT  channels_last features through the LDS-staged kernel
+//   DTC_ROIALIGN_LDS_KB (52)  DTC_RA_CHBLOCK (128 / 64)  DTC_RA_NO_XCD  DTC_RA_NO_CTS64  DTC_RA_NO_PAIRS  DTC_RA_PAIRS32
+struct RoiAlignConfig {
+  bool tile = true, general = false, nhwc_direct = true, xcd = true, cts64 = true;
+  int pair_loads = 1, ch_block = 0, lds_bytes = 52 * 1024;
+};
+static const RoiAlignConfig& roi_align_config() {
+  static const RoiAlignConfig cfg = [] {
+    RoiAlignConfig c;
+    if (const char* e = getenv("DTC_ROIALIGN_TILE")) c.tile = e[0] != '0';
+    c.general = getenv("DTC_ROIALIGN_GENERAL") != nullptr;
+    c.nhwc_direct = getenv("DTC_ROIALIGN_NO_NHWC_DIRECT") == nullptr;
+    c.xcd = getenv("DTC_RA_NO_XCD") == nullptr;
+    c.cts64 = getenv("DTC_RA_NO_CTS64") == nullptr;      // 64-channel sub-tiles for windows <= 128 px: +4 % on the bench workload
+    // 1: pixel-pair loads for 2-byte features; 2 (DTC_RA_PAIRS32=1): for fp32 features too (dwordx2 per lane, measured slower)
+    c.pair_loads = getenv("DTC_RA_NO_PAIRS") != nullptr ? 0 : (getenv("DTC_RA_PAIRS32") != nullptr ? 2 : 1);
+    if (const char* e = getenv("DTC_RA_CHBLOCK")) { const int v = atoi(e); if (v >= 64 && v % 64 == 0) c.ch_block = v; }
+    if (const char* e = getenv("DTC_ROIALIGN_LDS_KB")) { const int v = atoi(e); if (v >= 16 && v <= 160) c.lds_bytes = v * 1024; }
+    return c;
+  }();
+  return cfg;
+}
+
 template <typename TIn, typename TOut>
 static int launch_nhwc(const RoiAlignParams& p, hipStream_t stream) {
   if (p.n_rois == 0) return DTC_OK;
   const size_t smem = (size_t)kLdsTableFloats * 4 + (size_t)64 * p.pooled_h * p.pooled_w * 4 + 16;
-  static bool raised = false;
-  if (!raised && smem > 32 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_nhwc<TIn, TOut>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
-    raised = true;
-  }
+  static std::once_flag once;
+  static hipError_t rc = hipSuccess;
+  std::call_once(once, [] { rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_nhwc<TIn, TOut>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+  if (rc != hipSuccess) return DTC_ELAUNCH;
   const int nct = ceil_div(p.channels, 64);
   hipLaunchKernelGGL((roi_align_fwd_nhwc<TIn, TOut>), dim3((unsigned)p.n_rois * nct), dim3(kRoiAlignThreads), smem, stream, p);
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Wave-specialised kernel (NCHW features, the reference's layout).
-//
-// In roi_align_fwd_lds every wave both stages and computes, so the ~32 prefetch registers of the staging are live across
-// the compute phase (the 2x2 sample loop cannot be unrolled without spilling: no ILP on the LDS reads) and the gather
-// queue drains while the waves compute.  Here a 512-thread workgroup is split by ROLE:
-//   waves 0-3  LOADERS   only move data: global -> registers (two sub-tiles ahead) -> LDS window (pixel-major, [pix][cts+4])
-//   waves 4-7  COMPUTERS only pool: compute wave w owns channel quad w of the sub-tile for ALL bins (lane <-> bin), with
-//              the 2x2 sampling grid fully unrolled (16 ds_read_b128 in flight), transposes its [4][bins] results through a
-//              private LDS slab (wave-level ordering only) and stores them as one contiguous run.
-// Two LDS windows: loaders fill window (i+1)%2 while computers read window i%2; ONE workgroup barrier per sub-tile hands
-// a window over (both roles execute the same number of barriers, so there is nothing to deadlock on).  When two windows do
-// not fit, one window and two barriers per sub-tile are used.  Same arithmetic, same order: bit-identical output.
-// ---------------------------------------------------------------------------------------------------------------------
-#ifndef DTC_WS_SETS
-#define DTC_WS_SETS 1
-#endif
-constexpr int kWsThreads = 512;
-constexpr int kWsLoaders = 256;
-
-template <typename TIn, int K, int G>
-struct WsLoader {
-  float v[2][G][K];   // two register sets = two sub-tiles in flight
-  uint32_t voff[K];
-  int32_t lbase[K];
-  int cl, nk;
-  int64_t stride_c;
-  __device__ __forceinline__ void init(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int npix, int cts) {
-    const int tid = threadIdx.x;                 // loaders are threads [0, 256)
-    const int pl = tid & 15, wv = tid >> 6;
-    cl = (tid >> 4) & 3;
-    stride_c = L.stride_c;
-    const int ctp = cts + kLdsPad;
-    nk = ceil_div(ceil_div(npix, 16), kWsLoaders / 64);
-    const int q64 = 64 / ww, r64 = 64 - q64 * ww;
-    int pix = wv * 16 + pl;
-    int py = pix / ww, px = pix - py * ww;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      const bool ok = pix < npix;
-      const int ly = ok ? py : wh - 1, lx = ok ? px : ww - 1;
-      const int lp = ok ? pix : npix;                              // lanes past the window write the dummy pixel slot
-      voff[k] = (uint32_t)(((int64_t)(y0 + ly) * L.stride_h + (int64_t)(x0 + lx) * L.stride_w + (int64_t)cl * L.stride_c) *
-                           (int64_t)sizeof(TIn));
-      lbase[k] = lp * ctp + cl;
-      pix += 64; px += r64; py += q64;
-      if (px >= ww) { px -= ww; py++; }
-    }
-  }
-  template <int S>
-  __device__ __forceinline__ void issue(const TIn* cbase, int cts, int nvalid) {
-    const char* cb = reinterpret_cast<const char*>(cbase);
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-      if (4 * g < cts) {
-        const int c = min(4 * g + cl, nvalid - 1) - cl;          // channel tail: clamp the plane, never stored
-        const char* gb = cb + (int64_t)c * stride_c * (int64_t)sizeof(TIn);
-#pragma unroll
-        for (int k = 0; k < K; k++)
-          if (k < nk) v[S][g][k] = to_f32<TIn>(*reinterpret_cast<const TIn*>(gb + voff[k]));
-      }
-    }
-  }
-  template <int S>
-  __device__ __forceinline__ void commit(float* win, int cts) {
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-      if (4 * g < cts) {
-#pragma unroll
-        for (int k = 0; k < K; k++)
-          if (k < nk) win[lbase[k] + 4 * g] = v[S][g][k];
-      }
-    }
-  }
-};
-
-struct WsGeom {
-  const LdsAxis* ytab; const LdsAxis* xtab;
-  float* win0; float* win1;      // win1 == win0 in single-window mode
-  float* slabs;                  // 4 private slabs of [4][bins]
-  int cts, bins, gh, gw, pooled_w, nc, nbuf;
-  float count, inv_count;
-};
-
-template <typename TIn, typename Loader>
-__device__ __forceinline__ void ws_loader_role(Loader& ld, const WsGeom& G, const TIn* cbase, int64_t stride_c) {
-  const int npass = ceil_div(G.nc, G.cts);
-  ld.template issue<0>(cbase, G.cts, min(G.cts, G.nc));
-#if DTC_WS_SETS == 1
-  for (int i = 0; i < npass; i++) {
-    ld.template commit<0>((i & 1) ? G.win1 : G.win0, G.cts);
-    if (i + 1 < npass) ld.template issue<0>(cbase + (int64_t)(i + 1) * G.cts * stride_c, G.cts, min(G.cts, G.nc - (i + 1) * G.cts));
-    __syncthreads();
-    if (G.nbuf == 1) __syncthreads();
-  }
-  return;
-#endif
-  if (npass > 1) ld.template issue<1>(cbase + (int64_t)G.cts * stride_c, G.cts, min(G.cts, G.nc - G.cts));
-  for (int i = 0; i < npass; i += 2) {
-    // even sub-tile: register set 0 -> window 0
-    ld.template commit<0>(G.win0, G.cts);
-    if (i + 2 < npass) ld.template issue<0>(cbase + (int64_t)(i + 2) * G.cts * stride_c, G.cts, min(G.cts, G.nc - (i + 2) * G.cts));
-    __syncthreads();                                   // B(i): window 0 published
-    if (G.nbuf == 1) __syncthreads();                  // single window: wait until the computers are done with it
-    if (i + 1 < npass) {
-      ld.template commit<1>(G.win1, G.cts);
-      if (i + 3 < npass) ld.template issue<1>(cbase + (int64_t)(i + 3) * G.cts * stride_c, G.cts, min(G.cts, G.nc - (i + 3) * G.cts));
-      __syncthreads();                                 // B(i+1)
-      if (G.nbuf == 1) __syncthreads();
-    }
-  }
-}
-
-template <typename TOut>
-__device__ __forceinline__ void ws_compute_role(const WsGeom& G, TOut* out) {
-  const int ctid = threadIdx.x - kWsLoaders;
-  const int w = ctid >> 6, lane = ctid & 63;            // compute wave w <-> channel quad w of the sub-tile
-  const int quads = G.cts >> 2;                         // 4 (cts 16) or 2 (cts 8): waves >= quads idle in compute
-  float* slab = G.slabs + w * 4 * G.bins;
-  const int npass = ceil_div(G.nc, G.cts);
-  for (int i = 0; i < npass; i++) {
-    __syncthreads();                                    // B(i): this sub-tile's window is published
-    const float* wq = ((i & 1) ? G.win1 : G.win0) + w * 4;
-    const int cs = i * G.cts + w * 4;                   // first channel (inside the workgroup's block) of my quad
-    if (w < quads && cs < G.nc) {
-      for (int bin = lane; bin < G.bins; bin += 64) {
-        const int ph = bin / G.pooled_w, pw = bin - ph * G.pooled_w;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        if (G.gh == 2 && G.gw == 2) {
-          const LdsAxis x0e = G.xtab[pw * 2], x1e = G.xtab[pw * 2 + 1];
-          const LdsAxis y0e = G.ytab[ph * 2], y1e = G.ytab[ph * 2 + 1];
-          float4 t[16];
-          t[0] = *reinterpret_cast<const float4*>(wq + y0e.lo + x0e.lo); t[1] = *reinterpret_cast<const float4*>(wq + y0e.lo + x0e.hi);
-          t[2] = *reinterpret_cast<const float4*>(wq + y0e.hi + x0e.lo); t[3] = *reinterpret_cast<const float4*>(wq + y0e.hi + x0e.hi);
-          t[4] = *reinterpret_cast<const float4*>(wq + y0e.lo + x1e.lo); t[5] = *reinterpret_cast<const float4*>(wq + y0e.lo + x1e.hi);
-          t[6] = *reinterpret_cast<const float4*>(wq + y0e.hi + x1e.lo); t[7] = *reinterpret_cast<const float4*>(wq + y0e.hi + x1e.hi);
-          t[8] = *reinterpret_cast<const float4*>(wq + y1e.lo + x0e.lo); t[9] = *reinterpret_cast<const float4*>(wq + y1e.lo + x0e.hi);
-          t[10] = *reinterpret_cast<const float4*>(wq + y1e.hi + x0e.lo); t[11] = *reinterpret_cast<const float4*>(wq + y1e.hi + x0e.hi);
-          t[12] = *reinterpret_cast<const float4*>(wq + y1e.lo + x1e.lo); t[13] = *reinterpret_cast<const float4*>(wq + y1e.lo + x1e.hi);
-          t[14] = *reinterpret_cast<const float4*>(wq + y1e.hi + x1e.lo); t[15] = *reinterpret_cast<const float4*>(wq + y1e.hi + x1e.hi);
-#pragma unroll
-          for (int sidx = 0; sidx < 4; sidx++) {   // (iy, ix) = (0,0) (0,1) (1,0) (1,1): the reference's accumulation order
-            const LdsAxis& y = (sidx < 2) ? y0e : y1e;
-            const LdsAxis& x = (sidx & 1) ? x1e : x0e;
-            const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;      // roi_align_cpu_loop.cpp:95
-            const float4 v1 = t[sidx * 4], v2 = t[sidx * 4 + 1], v3 = t[sidx * 4 + 2], v4 = t[sidx * 4 + 3];
-            a0 += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;                              // :208-211
-            a1 += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
-            a2 += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
-            a3 += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
-          }
-        } else {
-          for (int iy = 0; iy < G.gh; iy++) {
-            const LdsAxis y = G.ytab[ph * G.gh + iy];
-            for (int ix = 0; ix < G.gw; ix++) {
-              const LdsAxis x = G.xtab[pw * G.gw + ix];
-              const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;
-              const float4 v1 = *reinterpret_cast<const float4*>(wq + y.lo + x.lo);
-              const float4 v2 = *reinterpret_cast<const float4*>(wq + y.lo + x.hi);
-              const float4 v3 = *reinterpret_cast<const float4*>(wq + y.hi + x.lo);
-              const float4 v4 = *reinterpret_cast<const float4*>(wq + y.hi + x.hi);
-              a0 += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
-              a1 += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
-              a2 += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
-              a3 += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
-            }
-          }
-        }
-        float* so = slab + bin;
-        if (G.inv_count != 0.f) { so[0] = a0 * G.inv_count; so[G.bins] = a1 * G.inv_count; so[2 * G.bins] = a2 * G.inv_count; so[3 * G.bins] = a3 * G.inv_count; }
-        else { so[0] = fdiv(a0, G.count); so[G.bins] = fdiv(a1, G.count); so[2 * G.bins] = fdiv(a2, G.count); so[3 * G.bins] = fdiv(a3, G.count); }   // :216
-      }
-      // private slab: LDS operations of ONE wave complete in issue order, so after the wait every lane sees the wave's writes
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      const int nch = min(4, G.nc - cs);
-      const int n_out = nch * G.bins;
-      TOut* og = out + (size_t)cs * G.bins;
-      if (sizeof(TOut) == 4 && ((reinterpret_cast<uintptr_t>(og) & 15) == 0)) {
-        const int n4 = n_out >> 2;
-        for (int j = lane; j < n4; j += 64) reinterpret_cast<float4*>(og)[j] = reinterpret_cast<const float4*>(slab)[j];
-        for (int j = (n4 << 2) + lane; j < n_out; j += 64) og[j] = from_f32<TOut>(slab[j]);
-      } else {
-        for (int j = lane; j < n_out; j += 64) og[j] = from_f32<TOut>(slab[j]);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next sub-tile overwrites it
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (G.nbuf == 1) __syncthreads();                   // single window: hand it back to the loaders
-  }
-}
-
-#ifndef DTC_WS_MINW
-#define DTC_WS_MINW 4
-#endif
-template <typename TIn, typename TOut>
-__global__ __launch_bounds__(kWsThreads, DTC_WS_MINW) void roi_align_fwd_ws(RoiAlignParams p, int lds_floats) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* lds = reinterpret_cast<float*>(smem);
-  AxisEntry* ytab = reinterpret_cast<AxisEntry*>(smem);
-  const int nct = ceil_div(p.channels, p.ch_block);
-  const int wi = xcd_work_item(blockIdx.x, gridDim.x, p.xcd_remap);
-  const int ri = wi / nct;
-  const int c0 = (wi - ri * nct) * p.ch_block;
-  const int nc = min(p.ch_block, p.channels - c0);
-  const int bins = p.pooled_h * p.pooled_w;
-  const int tid = threadIdx.x;
-  const RoiHead hd = load_roi_head(p, ri);
-  const int r = hd.r, lvl = hd.lvl, b = hd.b;
-  TOut* out = reinterpret_cast<TOut*>(p.out) + ((size_t)r * p.channels + c0) * bins;
-  if (lvl < 0 || lvl >= p.n_levels) {
-    for (int o = tid; o < nc * bins; o += kWsThreads) out[o] = from_f32<TOut>(0.f);
-    return;
-  }
-  const dtc_feat_level L = p.lv[lvl];
-  const float sw = hd.sw, sh = hd.sh, bin_h = hd.bin_h, bin_w = hd.bin_w, count = hd.count;
-  const int gh = hd.gh, gw = hd.gw;
-  const int ny = p.pooled_h * gh, nx = p.pooled_w * gw;
-  const bool tab_ok = (ny + nx) * 4 <= kLdsTableFloats;
-  AxisEntry* xtab = ytab + ny;
-  if (tab_ok) {
-    for (int t = tid; t < ny + nx; t += kWsThreads) {
-      if (t < ny) ytab[t] = make_axis(sh, bin_h, t / gh, t % gh, gh, L.height);
-      else { const int u = t - ny; xtab[u] = make_axis(sw, bin_w, u / gw, u % gw, gw, L.width); }
-    }
-  }
-  __syncthreads();
-  const TIn* fbase = reinterpret_cast<const TIn*>(L.data) + (int64_t)b * L.stride_n;
-  int y0 = 0, x0 = 0, ww = 1, wh = 1, npix = 0, cts = 0, nbuf = 0;
-  const int slab_floats = 4 * 4 * bins;                 // 4 compute waves x [4][bins]
-  if (tab_ok) {
-    y0 = ytab[0].lo; x0 = xtab[0].lo;
-    ww = xtab[nx - 1].hi - x0 + 1; wh = ytab[ny - 1].hi - y0 + 1;
-    npix = ww * wh;
-    const int avail = lds_floats - kLdsTableFloats - slab_floats;
-    // prefer two windows of 16 channels, then one window of 16, then one of 8; per-thread share <= 32 registers per set
-    if (npix <= kLdsMaxPix) {
-      if (npix * 16 <= 8192 && 2 * (npix + 1) * (16 + kLdsPad) <= avail) { cts = 16; nbuf = 2; }
-      else if (npix * 16 <= 8192 && (npix + 1) * (16 + kLdsPad) <= avail) { cts = 16; nbuf = 1; }
-      else if (2 * (npix + 1) * (8 + kLdsPad) <= avail) { cts = 8; nbuf = 2; }
-      else if ((npix + 1) * (8 + kLdsPad) <= avail) { cts = 8; nbuf = 1; }
-    }
-  }
-  if (cts == 0) {
-    for (int o = tid; o < nc * bins; o += kWsThreads) {   // oversize window / grid: per-output gather (same arithmetic)
-      const int c = o / bins, bin = o - c * bins;
-      const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
-      const TIn* d = fbase + (int64_t)(c0 + c) * L.stride_c;
-      float acc = 0.f;
-      for (int iy = 0; iy < gh; iy++) {
-        const AxisEntry y = tab_ok ? ytab[ph * gh + iy] : make_axis(sh, bin_h, ph, iy, gh, L.height);
-        const int64_t ylo = (int64_t)y.lo * L.stride_h, yhi = (int64_t)y.hi * L.stride_h;
-        for (int ix = 0; ix < gw; ix++) {
-          const AxisEntry x = tab_ok ? xtab[pw * gw + ix] : make_axis(sw, bin_w, pw, ix, gw, L.width);
-          const int64_t xlo = (int64_t)x.lo * L.stride_w, xhi = (int64_t)x.hi * L.stride_w;
-          const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;
-          acc += w1 * to_f32<TIn>(d[ylo + xlo]) + w2 * to_f32<TIn>(d[ylo + xhi]) + w3 * to_f32<TIn>(d[yhi + xlo]) +
-                 w4 * to_f32<TIn>(d[yhi + xhi]);
-        }
-      }
-      out[o] = from_f32<TOut>(fdiv(acc, count));
-    }
-    return;
-  }
-  __syncthreads();
-  const int ctp = cts + kLdsPad;
-  LdsAxis* yl = reinterpret_cast<LdsAxis*>(ytab);
-  LdsAxis* xl = reinterpret_cast<LdsAxis*>(xtab);
-  if (tid < ny) { AxisEntry e = ytab[tid]; LdsAxis o; o.lo = (e.lo - y0) * ww * ctp; o.hi = (e.hi - y0) * ww * ctp; o.l = e.l; o.h = e.h; yl[tid] = o; }
-  else if (tid < ny + nx) { AxisEntry e = ytab[tid]; LdsAxis o; o.lo = (e.lo - x0) * ctp; o.hi = (e.hi - x0) * ctp; o.l = e.l; o.h = e.h; yl[tid] = o; }
-  WsGeom G;
-  G.ytab = yl; G.xtab = xl;
-  G.slabs = lds + kLdsTableFloats;
-  G.win0 = G.slabs + slab_floats;
-  G.win1 = nbuf == 2 ? G.win0 + (npix + 1) * ctp : G.win0;
-  G.cts = cts; G.bins = bins; G.gh = gh; G.gw = gw; G.pooled_w = p.pooled_w; G.nc = nc; G.nbuf = nbuf;
-  G.count = count; G.inv_count = hd.inv_count;
-  __syncthreads();                                      // tables rewritten
-  if (tid < kWsLoaders) {
-    const TIn* cbase = fbase + (int64_t)c0 * L.stride_c;
-    const int nk = ceil_div(ceil_div(npix, 16), kWsLoaders / 64);
-    if (nk <= 4) { WsLoader<TIn, 4, 4> ld; ld.init(L, y0, x0, ww, wh, npix, cts); ws_loader_role<TIn>(ld, G, cbase, L.stride_c); }
-    else if (nk <= 8) { WsLoader<TIn, 8, 4> ld; ld.init(L, y0, x0, ww, wh, npix, cts); ws_loader_role<TIn>(ld, G, cbase, L.stride_c); }
-    else { WsLoader<TIn, 16, 2> ld; ld.init(L, y0, x0, ww, wh, npix, cts); ws_loader_role<TIn>(ld, G, cbase, L.stride_c); }
-  } else {
-    ws_compute_role<TOut>(G, out);
-  }
-}
-
-template <typename TIn, typename TOut>
-static int launch_ws(const RoiAlignParams& p, hipStream_t stream, int lds_b) {
-  if (p.n_rois == 0) return DTC_OK;
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_ws<TIn, TOut>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
-    raised = true;
-  }
-  const int nct = ceil_div(p.channels, p.ch_block);
-  hipLaunchKernelGGL((roi_align_fwd_ws<TIn, TOut>), dim3((unsigned)p.n_rois * nct), dim3(kWsThreads), lds_b, stream, p,
-                     lds_b / 4);
-  DTC_CHECK_LAUNCH();
-  return DTC_OK;
-}
-
-static int lds_bytes();
-
-// ---------------------------------------------------------------------------------------------------------------------
-// LDS-DMA kernel (NCHW fp32 features, the reference's layout): the box/mask-head fast path.
-//
-// The register-prefetch kernel above is bound by bytes-in-flight: ~32 prefetch registers per lane x 12 waves per CU cover
-// ~1.5 us of L2 latency and no more (PMC: 54 % of wave-cycles waiting).  Here the window is staged with
-// `global_load_lds_dword` (direct global->LDS DMA): no staging VGPRs, no ds_write pass, no per-element VALU, and a whole
-// next sub-tile (~20 KB per workgroup, x3 workgroups per CU) is in flight while the current one is computed.
-//   * LDS image is CHANNEL-major: plane c = [PS] floats, PS = 64*ceil(npix/64) + 1.  A DMA instruction writes 64 consecutive
-//     floats = 64 consecutive window pixels of one plane (lane-linear destination, per-lane source address), i.e. 2-3
-//     coalesced row pieces per instruction;
-//   * compute: lane <-> (channel, bin): a tap is one ds_read_b32 at  ch*PS + pixel_offset ; PS is odd, so the CT channels
-//     of a bin hit distinct banks.  Weights and offsets come from the per-axis LDS tables;
-//   * double buffer: DMA of sub-tile i+1 is issued right after the barrier that publishes sub-tile i; every wave waits
-//     vmcnt(0) before that barrier (LDS-DMA data is ordered for a ds_read only by the issuer's vmcnt + a barrier).
-// Arithmetic and accumulation order are those of the reference CPU loop: bit-identical output.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int kDmaMaxChunks = 16;   // 64-pixel chunks per plane: windows up to 1024 pixels
-
-__device__ __forceinline__ void dma_load_dword(const float* gptr, float* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
-}
-
-template <typename TOut>
-__global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_dma(RoiAlignParams p, int lds_floats) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* lds = reinterpret_cast<float*>(smem);
-  AxisEntry* ytab = reinterpret_cast<AxisEntry*>(smem);
-  const int nct = ceil_div(p.channels, p.ch_block);
-  const int wi = xcd_work_item(blockIdx.x, gridDim.x, p.xcd_remap);
-  const int ri = wi / nct;
-  const int c0 = (wi - ri * nct) * p.ch_block;
-  const int nc = min(p.ch_block, p.channels - c0);
-  const int bins = p.pooled_h * p.pooled_w;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const RoiHead hd = load_roi_head(p, ri);
-  const int r = hd.r, lvl = hd.lvl, b = hd.b;
-  TOut* out = reinterpret_cast<TOut*>(p.out) + ((size_t)r * p.channels + c0) * bins;
-  if (lvl < 0 || lvl >= p.n_levels) {
-    for (int o = tid; o < nc * bins; o += kRoiAlignThreads) out[o] = from_f32<TOut>(0.f);
-    return;
-  }
-  const dtc_feat_level L = p.lv[lvl];
-  const float sw = hd.sw, sh = hd.sh, bin_h = hd.bin_h, bin_w = hd.bin_w, count = hd.count, inv_count = hd.inv_count;
-  const int gh = hd.gh, gw = hd.gw;
-  const int ny = p.pooled_h * gh, nx = p.pooled_w * gw;
-  const bool tab_ok = (ny + nx) * 4 <= kLdsTableFloats;
-  AxisEntry* xtab = ytab + ny;
-  if (tab_ok) {
-    for (int t = tid; t < ny + nx; t += kRoiAlignThreads) {
-      if (t < ny) ytab[t] = make_axis(sh, bin_h, t / gh, t % gh, gh, L.height);
-      else { const int u = t - ny; xtab[u] = make_axis(sw, bin_w, u / gw, u % gw, gw, L.width); }
-    }
-  }
-  __syncthreads();
-  const float* fbase = reinterpret_cast<const float*>(L.data) + (int64_t)b * L.stride_n;
-  int y0 = 0, x0 = 0, ww = 1, wh = 1, npix = 0, ct = 0, nch = 0, PS = 0;
-  if (tab_ok) {
-    y0 = ytab[0].lo; x0 = xtab[0].lo;
-    ww = xtab[nx - 1].hi - x0 + 1; wh = ytab[ny - 1].hi - y0 + 1;
-    npix = ww * wh;
-    nch = (npix + 63) >> 6;
-    PS = nch * 64 + 1;
-#pragma unroll
-    for (int c = 32; c >= 8; c >>= 1)
-      if (ct == 0 && nch <= kDmaMaxChunks && kLdsTableFloats + c * bins + 2 * c * PS <= lds_floats) ct = c;
-  }
-  if (ct == 0) {
-    // oversize window / sampling grid: per-output gather straight from global (same arithmetic)
-    for (int o = tid; o < nc * bins; o += kRoiAlignThreads) {
-      const int c = o / bins, bin = o - c * bins;
-      const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
-      const float* d = fbase + (int64_t)(c0 + c) * L.stride_c;
-      float acc = 0.f;
-      for (int iy = 0; iy < gh; iy++) {
-        const AxisEntry y = tab_ok ? ytab[ph * gh + iy] : make_axis(sh, bin_h, ph, iy, gh, L.height);
-        const int64_t ylo = (int64_t)y.lo * L.stride_h, yhi = (int64_t)y.hi * L.stride_h;
-        for (int ix = 0; ix < gw; ix++) {
-          const AxisEntry x = tab_ok ? xtab[pw * gw + ix] : make_axis(sw, bin_w, pw, ix, gw, L.width);
-          const int64_t xlo = (int64_t)x.lo * L.stride_w, xhi = (int64_t)x.hi * L.stride_w;
-          const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;
-          acc += w1 * d[ylo + xlo] + w2 * d[ylo + xhi] + w3 * d[yhi + xlo] + w4 * d[yhi + xhi];
-        }
-      }
-      out[o] = from_f32<TOut>(fdiv(acc, count));
-    }
-    return;
-  }
-  __syncthreads();
-  // tables -> window-relative pixel offsets (in place)
-  LdsAxis* yl = reinterpret_cast<LdsAxis*>(ytab);
-  LdsAxis* xl = reinterpret_cast<LdsAxis*>(xtab);
-  if (tid < ny) { AxisEntry e = ytab[tid]; LdsAxis o; o.lo = (e.lo - y0) * ww; o.hi = (e.hi - y0) * ww; o.l = e.l; o.h = e.h; yl[tid] = o; }
-  else if (tid < ny + nx) { AxisEntry e = ytab[tid]; LdsAxis o; o.lo = e.lo - x0; o.hi = e.hi - x0; o.l = e.l; o.h = e.h; yl[tid] = o; }
-  float* slab = lds + kLdsTableFloats;            // [ct][bins]
-  float* buf0 = slab + ct * bins;                 // [ct][PS]
-  float* buf1 = buf0 + ct * PS;
-  // per-lane source offsets (elements inside one plane) of the window pixels this lane feeds, one per 64-pixel chunk
-  int32_t goff[kDmaMaxChunks];
-  {
-    const int q64 = 64 / ww, r64 = 64 - q64 * ww;
-    int pix = lane, py = lane / ww, px = lane - py * ww;
-#pragma unroll
-    for (int k = 0; k < kDmaMaxChunks; k++) {
-      const bool ok = pix < npix;
-      const int ly = ok ? py : wh - 1, lx = ok ? px : ww - 1;    // lanes past the window re-read its last pixel (pad area)
-      goff[k] = (int32_t)((int64_t)(y0 + ly) * L.stride_h + (int64_t)(x0 + lx) * L.stride_w);
-      pix += 64; px += r64; py += q64;
-      if (px >= ww) { px -= ww; py++; }
-    }
-  }
-  const float* cbase = fbase + (int64_t)c0 * L.stride_c;
-  auto issue = [&](int cs, float* buf) {
-    for (int c = wv; c < ct; c += kRoiAlignThreads / 64) {
-      const int cc = min(cs + c, nc - 1);                       // channel tail: duplicate the last plane, never stored
-      const float* plane = cbase + (int64_t)cc * L.stride_c;
-      float* dst = buf + c * PS;
-#pragma unroll
-      for (int k = 0; k < kDmaMaxChunks; k++)
-        if (k < nch) dma_load_dword(plane + goff[k], dst + k * 64);
-    }
-  };
-  const int ctm = ct - 1, ctsh = ct == 32 ? 5 : (ct == 16 ? 4 : 3);
-  const int ch = lane & ctm, sub = lane >> ctsh, nb = 64 >> ctsh;   // lane -> (channel of the sub-tile, bin slot)
-  const int npass = ceil_div(nc, ct);
-  issue(0, buf0);
-  for (int i = 0; i < npass; i++) {
-    float* buf = (i & 1) ? buf1 : buf0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's DMA pieces (and slab stores) have landed
-    __syncthreads();                                            // ... everybody's: buf is readable, slab/other buffer free
-    if (i + 1 < npass) issue((i + 1) * ct, (i & 1) ? buf0 : buf1);
-    const float* plane = buf + ch * PS;
-    for (int bin0 = 0; bin0 < bins; bin0 += (kRoiAlignThreads / 64) * nb) {
-      const int bin = bin0 + wv * nb + sub;
-      if (bin < bins) {
-        const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
-        float acc = 0.f;
-        for (int iy = 0; iy < gh; iy++) {
-          const LdsAxis y = yl[ph * gh + iy];
-          for (int ix = 0; ix < gw; ix++) {
-            const LdsAxis x = xl[pw * gw + ix];
-            const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;   // roi_align_cpu_loop.cpp:95
-            acc += w1 * plane[y.lo + x.lo] + w2 * plane[y.lo + x.hi] + w3 * plane[y.hi + x.lo] +
-                   w4 * plane[y.hi + x.hi];                                                // :208-211
-          }
-        }
-        slab[ch * bins + bin] = inv_count != 0.f ? acc * inv_count : fdiv(acc, count);     // :216
-      }
-    }
-    __syncthreads();
-    const int cs = i * ct;
-    const int nvalid = min(ct, nc - cs);
-    TOut* og = out + (size_t)cs * bins;
-    const int n_out = nvalid * bins;
-    if (sizeof(TOut) == 4 && ((reinterpret_cast<uintptr_t>(og) & 15) == 0)) {
-      const int n4 = n_out >> 2;
-      for (int j = tid; j < n4; j += kRoiAlignThreads) reinterpret_cast<float4*>(og)[j] = reinterpret_cast<const float4*>(slab)[j];
-      for (int j = (n4 << 2) + tid; j < n_out; j += kRoiAlignThreads) og[j] = from_f32<TOut>(slab[j]);
-    } else {
-      for (int j = tid; j < n_out; j += kRoiAlignThreads) og[j] = from_f32<TOut>(slab[j]);
-    }
-  }
-}
-
-template <typename TOut>
-static int launch_dma(const RoiAlignParams& p, hipStream_t stream, int lds_b) {
-  if (p.n_rois == 0) return DTC_OK;
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_dma<TOut>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
-    raised = true;
-  }
-  const int nct = ceil_div(p.channels, p.ch_block);
-  hipLaunchKernelGGL((roi_align_fwd_dma<TOut>), dim3((unsigned)p.n_rois * nct), dim3(kRoiAlignThreads), lds_b, stream, p,
-                     lds_b / 4);
-  DTC_CHECK_LAUNCH();
-  return DTC_OK;
-}
-
-static int lds_bytes() {
-  static int v = 0;
-  if (!v) { const char* e = getenv("DTC_ROIALIGN_LDS_KB"); v = (e ? atoi(e) : 52) * 1024; if (v < 16 * 1024 || v > 160 * 1024) v = 52 * 1024; }
-  return v;
-}
-
 template <typename TIn, typename TOut>
 static int launch_lds(const RoiAlignParams& p, hipStream_t stream) {
   if (p.n_rois == 0) return DTC_OK;
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_lds<TIn, TOut>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
-    raised = true;
-  }
+  static std::once_flag once;
+  static hipError_t rc = hipSuccess;
+  std::call_once(once, [] { rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_lds<TIn, TOut>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+  if (rc != hipSuccess) return DTC_ELAUNCH;
+  const int lds_b = roi_align_config().lds_bytes;
   const int nct = ceil_div(p.channels, p.ch_block);
-  hipLaunchKernelGGL((roi_align_fwd_lds<TIn, TOut>), dim3((unsigned)p.n_rois * nct), dim3(kRoiAlignThreads), lds_bytes(),
-                     stream, p, lds_bytes() / 4);
+  hipLaunchKernelGGL((roi_align_fwd_lds<TIn, TOut>), dim3((unsigned)p.n_rois * nct), dim3(kRoiAlignThreads), lds_b, stream, p,
+                     lds_b / 4);
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }
@@ -1363,6 +760,23 @@ static int launch_general(const RoiAlignParams& p, hipStream_t stream) {
   return DTC_OK;
 }
 
+enum { kKernNhwc, kKernLds, kKernGeneral };
+template <typename TIn, typename TOut>
+static int launch_kind(int kind, const RoiAlignParams& p, hipStream_t s) {
+  return kind == kKernNhwc ? launch_nhwc<TIn, TOut>(p, s) : kind == kKernLds ? launch_lds<TIn, TOut>(p, s) : launch_general<TIn, TOut>(p, s);
+}
+// (in, out) dtype pairs: fp32 accumulate always; f16 and bf16 do not mix
+static int launch_typed(int kind, const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t s) {
+  if (in_dtype == DTC_F32 && out_dtype == DTC_F32) return launch_kind<float, float>(kind, p, s);
+  if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return launch_kind<__half, float>(kind, p, s);
+  if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return launch_kind<__half, __half>(kind, p, s);
+  if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return launch_kind<float, __half>(kind, p, s);
+  if (in_dtype == DTC_BF16 && out_dtype == DTC_F32) return launch_kind<bf16_t, float>(kind, p, s);
+  if (in_dtype == DTC_BF16 && out_dtype == DTC_BF16) return launch_kind<bf16_t, bf16_t>(kind, p, s);
+  if (in_dtype == DTC_F32 && out_dtype == DTC_BF16) return launch_kind<float, bf16_t>(kind, p, s);
+  return DTC_EUNSUPPORTED;
+}
+
 }  // namespace dtc
 
 static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype, const float* rois,
@@ -1372,6 +786,7 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   if (!levels || n_levels < 1 || n_levels > DTC_MAX_LEVELS || channels < 1 || n_rois < 0 || pooled_h < 1 ||
       pooled_w < 1 || (roi_cols != 4 && roi_cols != 5) || (n_rois > 0 && ((!rois && !roi_desc) || !out)))
     return DTC_EINVAL;
+  const dtc::RoiAlignConfig& cfg = dtc::roi_align_config();
   dtc::RoiAlignParams p;
   for (int i = 0; i < n_levels; i++) {
     if (!levels[i].data || levels[i].height < 1 || levels[i].width < 1) return DTC_EINVAL;
@@ -1381,86 +796,29 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   p.n_levels = n_levels; p.channels = channels; p.roi_cols = roi_cols; p.n_rois = n_rois;
   p.pooled_h = pooled_h; p.pooled_w = pooled_w; p.sampling_ratio = sampling_ratio;
   p.ch_tile = channels < 64 ? channels : 64;
-  // channels per workgroup of the LDS kernel: 128 (the per-RoI setup is paid once per 128 channels and the register
-  // prefetch pipeline runs across more passes) unless that leaves too few workgroups to fill 256 CUs x 3.
+  // channels per workgroup of the RoI-stationary LDS kernel: 128 (the per-RoI setup is paid once per 128 channels and the
+  // register prefetch pipeline runs across more passes) unless that leaves too few workgroups to fill 256 CUs x 3.
   // Measured on MI355X, 8000 RoIs x 256 ch: 64 -> 0.710 ms, 128 -> 0.704 ms, 256 -> 0.760 ms.
   p.ch_block = channels > 64 ? 128 : 64;
   if ((long long)n_rois * ((channels + p.ch_block - 1) / p.ch_block) < 3072) p.ch_block = 64;
-  if (getenv("DTC_RA_CHBLOCK")) p.ch_block = atoi(getenv("DTC_RA_CHBLOCK"));
-  p.xcd_remap = getenv("DTC_RA_NO_XCD") == nullptr;
-  p.row4 = getenv("DTC_RA_ROW4") != nullptr;      // measured neutral (0.73 vs 0.71 ms): off by default, A/B knob
-  p.cts64 = getenv("DTC_RA_NO_CTS64") == nullptr;   // 64-channel sub-tiles for windows <= 128 px: +4 % on the bench workload
-  // both measured (tools/tcp_probe_quad.sh): L1 accesses halve (187 M -> 91 M / 84 M per launch) but the line fills do not
-  // change (51.8 M) and the launch gets slower (0.755 -> 0.788 / 0.869 ms): off by default, kept as tested A/B knobs
-  // 1: pixel-pair loads for 2-byte features; 2 (DTC_RA_PAIRS32=1): for fp32 features too (dwordx2 per lane)
-  p.pair_loads = getenv("DTC_RA_NO_PAIRS") != nullptr ? 0 : (getenv("DTC_RA_PAIRS32") != nullptr ? 2 : 1);
-  p.quad_align = getenv("DTC_RA_QUAD") != nullptr;
-  p.row_slots = getenv("DTC_RA_ROWSLOTS") != nullptr;
+  if (cfg.ch_block) p.ch_block = cfg.ch_block;
+  p.xcd_remap = cfg.xcd; p.cts64 = cfg.cts64; p.pair_loads = cfg.pair_loads;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  // fixed sampling grid with small tables -> LDS-staged kernel; adaptive sampling (sampling_ratio <= 0) -> general kernel
   // LDS-staged kernel for every pooled size whose output slab fits; adaptive sampling (sampling_ratio <= 0) included
-  // (tables sized per RoI, oversize grids/windows fall back per workgroup).  DTC_ROIALIGN_GENERAL=1 forces the plain
-  // per-output gather kernel (kept as the reference implementation of the arithmetic and for A/B measurements).
+  // (tables sized per RoI, oversize grids / windows fall back per workgroup)
   const bool lds_ok = (sampling_ratio <= 0 || (pooled_h + pooled_w) * sampling_ratio * 4 <= dtc::kLdsTableFloats) &&
-                      (long long)pooled_h * pooled_w * 8 <= 4096 && getenv("DTC_ROIALIGN_GENERAL") == nullptr;
+                      (long long)pooled_h * pooled_w * 8 <= 4096 && !cfg.general;
   bool all_nhwc = channels > 1;
   for (int i = 0; i < n_levels; i++) all_nhwc = all_nhwc && levels[i].stride_c == 1;
-  // direct gather pays when a window pixel is re-used only a few times (7x7 bins x 2x2 samples over a ~300-pixel window:
-  // 2.5 taps per pixel, measured 0.50 vs 0.65 ms); with 14x14 bins (10 taps per pixel) staging the window in LDS wins
-  // (0.21 vs 0.37 ms), and the LDS kernel stages channels_last windows with 16-byte loads too.
+  // channels_last: direct gather pays when a window pixel is re-used only a few times (7x7 bins x 2x2 samples over a
+  // ~300-pixel window: 2.5 taps per pixel, measured 0.50 vs 0.65 ms); with 14x14 bins (10 taps per pixel) staging the window
+  // in LDS wins (0.21 vs 0.37 ms), and the LDS kernel stages channels_last windows with 16-byte loads too.
   const bool few_taps = sampling_ratio > 0 && (long long)pooled_h * pooled_w * sampling_ratio * sampling_ratio <= 256;
-  if (lds_ok && all_nhwc && few_taps && getenv("DTC_ROIALIGN_NO_NHWC_DIRECT") == nullptr) {
-    if (in_dtype == DTC_F32 && out_dtype == DTC_F32) return dtc::launch_nhwc<float, float>(p, s);
-    if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return dtc::launch_nhwc<__half, float>(p, s);
-    if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return dtc::launch_nhwc<__half, __half>(p, s);
-    if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return dtc::launch_nhwc<float, __half>(p, s);
-    if (in_dtype == DTC_BF16 && out_dtype == DTC_F32) return dtc::launch_nhwc<dtc::bf16_t, float>(p, s);
-    if (in_dtype == DTC_BF16 && out_dtype == DTC_BF16) return dtc::launch_nhwc<dtc::bf16_t, dtc::bf16_t>(p, s);
-    if (in_dtype == DTC_F32 && out_dtype == DTC_BF16) return dtc::launch_nhwc<float, dtc::bf16_t>(p, s);
-    return DTC_EUNSUPPORTED;
-  }
-  // Cluster-stationary kernel (roi_align_tile.hip): the default for sampling_ratio == 2 on NCHW (and mixed) layouts.
-  // DTC_ROIALIGN_TILE=0 selects the round-1 RoI-stationary kernel below for A/B runs (resolved once).
-  static const bool tile_on = [] { const char* e = getenv("DTC_ROIALIGN_TILE"); return !(e && e[0] == '0'); }();
-  if (tile_on && !all_nhwc && getenv("DTC_ROIALIGN_GENERAL") == nullptr && dtc::roi_align_tile_supported(p, in_dtype, out_dtype))
+  if (lds_ok && all_nhwc && few_taps && cfg.nhwc_direct) return dtc::launch_typed(dtc::kKernNhwc, p, in_dtype, out_dtype, s);
+  // NCHW (the reference's layout), sampling_ratio 2: the cluster-stationary kernel (roi_align_tile.hip)
+  if (cfg.tile && !all_nhwc && !cfg.general && dtc::roi_align_tile_supported(p, in_dtype, out_dtype))
     return dtc::launch_roi_align_tile(p, in_dtype, out_dtype, s);
-  // LDS-DMA variant: bit-exact and tested, but SLOWER on MI355X than the register-prefetch kernel (8000 RoIs: 0.84 vs
-  // 0.71 ms): with 4 bytes per lane a `global_load_lds_dword` moves only 256 B per instruction and a workgroup needs ~1200 of
-  // them per RoI -- the DMA issue rate, not bytes in flight, becomes the limit.  Kept behind DTC_ROIALIGN_DMA=1 for A/B runs.
-  // Wave-specialised variant (loader waves / compute waves, double-buffered windows): bit-exact and tested, measured
-  // 0.84 ms vs 0.80 ms for the default kernel on the same box (512-thread workgroups at 128 VGPRs -> 2 workgroups per CU;
-  // with two register sets and 194 VGPRs only one workgroup fits: 1.05 ms).  Kept behind DTC_ROIALIGN_WS=1 for A/B runs.
-  if (lds_ok && !all_nhwc && getenv("DTC_ROIALIGN_WS") != nullptr) {
-    const int lds_b = dtc::lds_bytes();
-    if (in_dtype == DTC_F32 && out_dtype == DTC_F32) return dtc::launch_ws<float, float>(p, s, lds_b);
-    if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return dtc::launch_ws<__half, float>(p, s, lds_b);
-    if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return dtc::launch_ws<__half, __half>(p, s, lds_b);
-    if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return dtc::launch_ws<float, __half>(p, s, lds_b);
-  }
-  if (lds_ok && in_dtype == DTC_F32 && !all_nhwc && getenv("DTC_ROIALIGN_DMA") != nullptr) {
-    int lds_b = dtc::lds_bytes();
-    if (out_dtype == DTC_F32) return dtc::launch_dma<float>(p, s, lds_b);
-    if (out_dtype == DTC_F16) return dtc::launch_dma<__half>(p, s, lds_b);
-    return DTC_EUNSUPPORTED;
-  }
-  if (lds_ok) {
-    if (in_dtype == DTC_F32 && out_dtype == DTC_F32) return dtc::launch_lds<float, float>(p, s);
-    if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return dtc::launch_lds<__half, float>(p, s);
-    if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return dtc::launch_lds<__half, __half>(p, s);
-    if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return dtc::launch_lds<float, __half>(p, s);
-    if (in_dtype == DTC_BF16 && out_dtype == DTC_F32) return dtc::launch_lds<dtc::bf16_t, float>(p, s);
-    if (in_dtype == DTC_BF16 && out_dtype == DTC_BF16) return dtc::launch_lds<dtc::bf16_t, dtc::bf16_t>(p, s);
-    if (in_dtype == DTC_F32 && out_dtype == DTC_BF16) return dtc::launch_lds<float, dtc::bf16_t>(p, s);
-    return DTC_EUNSUPPORTED;
-  }
-  if (in_dtype == DTC_F32 && out_dtype == DTC_F32) return dtc::launch_general<float, float>(p, s);
-  if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return dtc::launch_general<__half, float>(p, s);
-  if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return dtc::launch_general<__half, __half>(p, s);
-  if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return dtc::launch_general<float, __half>(p, s);
-  if (in_dtype == DTC_BF16 && out_dtype == DTC_F32) return dtc::launch_general<dtc::bf16_t, float>(p, s);
-  if (in_dtype == DTC_BF16 && out_dtype == DTC_BF16) return dtc::launch_general<dtc::bf16_t, dtc::bf16_t>(p, s);
-  if (in_dtype == DTC_F32 && out_dtype == DTC_BF16) return dtc::launch_general<float, dtc::bf16_t>(p, s);
-  return DTC_EUNSUPPORTED;
+  return dtc::launch_typed(lds_ok ? dtc::kKernLds : dtc::kKernGeneral, p, in_dtype, out_dtype, s);
 }
 
 DTC_API int dtc_roi_align_forward_ordered(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,

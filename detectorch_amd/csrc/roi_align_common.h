@@ -16,11 +16,8 @@ struct RoiAlignParams {
   void* out;
   int n_levels, channels, roi_cols, n_rois, pooled_h, pooled_w, sampling_ratio, ch_tile;
   int ch_block;   // channels per workgroup of the LDS kernel (multiple of 64): setup (tables, window) is paid once per block
-  int quad_align; // 1: widen staged windows to 4-pixel boundaries (aligned lane quads; see roi_align_fwd_lds)
-  int row_slots;  // 1: row-slot chunk enumeration (a row piece belongs to one wave-instruction)
   int pair_loads; // 1: 2-byte features are gathered as pixel pairs (StagerNCHW2)
   int cts64;      // 1: allow 64-channel sub-tiles (one bin per ds_read_b128 lane group: conflict-free taps)
-  int row4;       // 1: 16-byte row pieces for NCHW levels whose rows are 4-element aligned (StagerRow4)
   int xcd_remap;  // 1: workgroup -> work-item mapping keeps each XCD on a contiguous range of the visiting order
 };
 

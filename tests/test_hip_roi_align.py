@@ -179,16 +179,52 @@ def test_ordered_and_packed_entry_points(hip, oracle):
     assert np.array_equal(res[:200], ref) and not res[200].any()
 
 
-@pytest.mark.parametrize("env", ["DTC_ROIALIGN_WS", "DTC_ROIALIGN_DMA", "DTC_ROIALIGN_GENERAL", "DTC_RA_ROW4", "DTC_RA_NO_CTS64", "DTC_RA_QUAD", "DTC_RA_ROWSLOTS", "DTC_RA_PAIRS32"])
-def test_experimental_kernel_variants_bit_exact(hip, oracle, env, monkeypatch):
-    """The env-selected RoIAlign variants kept in the library (wave-specialised loader/compute kernel, LDS-DMA staging, the
-    general gather kernel) do the same arithmetic in the same order: bit-identical to the oracle, incl. channel tails."""
-    monkeypatch.setenv(env, "1")                         # read with getenv() at every dispatch
-    for (C, ph, sr, R, seed) in [(32, 7, 2, 200, 5), (130, 7, 2, 60, 6), (24, 14, 2, 60, 8), (20, 7, 0, 60, 9)]:
-        feats, rois5, lv, ref = _fpn_case(oracle, R, C, ph, sr, seed, batch=2)
-        out = hip.roi_align_forward([cu(f) for f in feats], synth.FPN_ROI_SCALES, cu(rois5), ph, ph, sr,
-                                    roi_levels=cu(lv)).cpu().numpy()
-        assert np.array_equal(out, ref), (env, C, ph, sr)
+_VARIANT_CHILD = r"""
+import sys, os, numpy as np, torch
+root = %r
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle")); sys.path.insert(0, os.path.join(root, "tests"))
+import oracle as orc
+from detectorch_amd import hip, synth
+import test_hip_roi_align as T
+for (C, ph, sr, R, seed) in [(32, 7, 2, 200, 5), (130, 7, 2, 60, 6), (24, 14, 2, 60, 8), (20, 7, 0, 60, 9), (256, 7, 2, 1600, 1007)]:
+    feats, rois5, lv, ref = T._fpn_case(orc, R, C, ph, sr, seed, batch=2)
+    for nhwc in (False, True):
+        tf = [T.cu(f) for f in feats]
+        if nhwc:
+            tf = [t.contiguous(memory_format=torch.channels_last) for t in tf]
+        out = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, T.cu(rois5), ph, ph, sr, roi_levels=T.cu(lv)).cpu().numpy()
+        assert np.array_equal(out, ref), (C, ph, sr, nhwc)
+    h16 = [T.cu(f).half() for f in feats]
+    ref16 = np.zeros_like(ref)
+    for l in range(4):
+        m = lv == l
+        if m.any():
+            ref16[m] = orc.roi_align_forward(h16[l].float().cpu().numpy(), rois5[m], ph, ph, synth.FPN_ROI_SCALES[l], sr)
+    out16 = hip.roi_align_forward(h16, synth.FPN_ROI_SCALES, T.cu(rois5), ph, ph, sr, roi_levels=T.cu(lv)).cpu().numpy()
+    assert np.array_equal(out16, ref16), ("fp16", C, ph, sr)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("env", ["DTC_ROIALIGN_TILE=0", "DTC_ROIALIGN_GENERAL=1", "DTC_ROIALIGN_TILE=0 DTC_RA_NO_CTS64=1",
+                                 "DTC_ROIALIGN_TILE=0 DTC_RA_PAIRS32=1", "DTC_ROIALIGN_TILE=0 DTC_RA_NO_PAIRS=1",
+                                 "DTC_ROIALIGN_NO_NHWC_DIRECT=1", "DTC_RA_TILE_NT=512", "DTC_RA_TILE_NT=1024 DTC_RA_TILE_MERGE=1000"])
+def test_kernel_variants_bit_exact_in_child_process(hip, oracle, env):
+    """Every RoIAlign kernel that stays in the library -- the cluster-stationary default in its three workgroup shapes, the
+    RoI-stationary LDS kernel with its stager options, the channels_last direct kernel, the per-output gather kernel -- does
+    the same float32 arithmetic in the same order: bit-identical to the oracle, fp32 / fp16, NCHW / channels_last, channel
+    tails, adaptive sampling, and the 1600 x 256 many-workgroup configuration.  The selecting knobs are resolved once per
+    process, so each setting runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for kv in env.split():
+        k, v = kv.split("=")
+        e[k] = v
+    r = subprocess.run([sys.executable, "-c", _VARIANT_CHILD % root], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, env + "\n" + r.stdout[-1500:] + r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("layout", ["nchw", "nhwc"])
@@ -220,7 +256,7 @@ def test_bfloat16_features_and_output(hip, oracle, layout):
 def test_full_channel_count_multilevel_batched_vs_oracle(hip, oracle, ph, R):
     """C = 256 (the real FPN channel count), all four levels, B = 2, enough RoIs x channel blocks that the launch takes the
     many-workgroup / 128-channel-block configuration bench.py runs (>= 3072 workgroups for the round-1 kernel), both pooled
-    sizes, for the default cluster-stationary kernel (the RoI-stationary A/B kernel: test_roi_stationary_kernel_subprocess).
+    sizes, for the default cluster-stationary kernel (the other kernels: test_kernel_variants_bit_exact_in_child_process).
     Bit-exact, in the plain order and in the (image, level, band, x) visiting order where clusters actually merge."""
     feats, rois5, lv, ref = _fpn_case(oracle, R, 256, ph, 2, 1000 + ph, batch=2)
     # visit in (image, level, y band, x) order like dtc_fpn_collect_distribute does, so clusters actually merge
@@ -232,29 +268,6 @@ def test_full_channel_count_multilevel_batched_vs_oracle(hip, oracle, ph, R):
                                     roi_order=None if o is None else cu(o)).cpu().numpy()
         assert np.abs(out - ref).max() <= TOL
         assert np.array_equal(out, ref)
-
-
-def test_roi_stationary_kernel_subprocess(hip, oracle, tmp_path):
-    """The round-1 RoI-stationary kernel (DTC_ROIALIGN_TILE=0, resolved once per process) on the same full-size cases, in a
-    child process: 1600 x 256 x 7x7 (ch_block 128 path: 1600 x 2 = 3200 workgroups) and 320 x 256 x 14x14."""
-    import subprocess
-    import sys
-    import os
-    code = r'''
-import sys, os, numpy as np, torch
-sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle")); sys.path.insert(0, os.path.join(%r, "tests"))
-import oracle as orc
-from detectorch_amd import hip, synth
-import test_hip_roi_align as T
-for ph, R in ((7, 1600), (14, 320)):
-    feats, rois5, lv, ref = T._fpn_case(orc, R, 256, ph, 2, 1000 + ph, batch=2)
-    out = hip.roi_align_forward([T.cu(f) for f in feats], synth.FPN_ROI_SCALES, T.cu(rois5), ph, ph, 2, roi_levels=T.cu(lv)).cpu().numpy()
-    assert np.array_equal(out, ref), ph
-print("ok")
-''' % ((os.path.dirname(os.path.dirname(os.path.abspath(__file__))),) * 3)
-    env = dict(os.environ, DTC_ROIALIGN_TILE="0")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_tile_kernel_edge_cases(hip, oracle):
