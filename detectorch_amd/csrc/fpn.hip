@@ -177,21 +177,25 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(Fpn
       if (r < p.top_n) {
         const int lvl = p.roi_levels[(size_t)b * p.top_n + r];
         const float* o = p.rois5 + ((size_t)b * p.top_n + r) * 5;
-        // (level, band of 32 feature rows, x centre, rank): RoIs that are neighbours in the order overlap in BOTH directions,
-        // so a 128-byte feature line (32 pixels of one channel row) is re-used by the next few RoIs while it is still in
-        // the XCD's L2 -- with a y-only order the concurrently pooled RoIs span the whole map width and a line is evicted
-        // before its next user arrives (EA reads per box-head launch: 1.79 GB -> see profiles/).
+        // Locality code of a RoI: (level | band of 2^band_log2 feature rows | x centre in feature pixels).  Neighbours in this
+        // order overlap in BOTH directions: K consecutive RoIs form a compact patch -- what the cluster-stationary RoIAlign
+        // kernel merges into one staged window -- and patches that follow each other share columns that are still in the
+        // XCD's L2.  (Interleaving two or four vertically adjacent bands per 32..256-pixel x cell, so that the rows bands share
+        // are re-read sooner, was measured in round 2: 0.404-0.441 ms per box-head launch against 0.391-0.396 for the plain
+        // order -- the patches merge less well -- and was dropped.)
         const uint32_t yc = (uint32_t)fminf(fmaxf((o[2] + o[4]) * 0.5f, 0.f), 65535.f);
         const uint32_t xc = (uint32_t)fminf(fmaxf((o[1] + o[3]) * 0.5f, 0.f), 65535.f);
         const uint32_t lv4 = lvl < 0 ? 15u : (uint32_t)lvl;
-        const uint32_t band = yc >> min((uint32_t)p.band_log2 + (uint32_t)p.k_min + lv4, 15u);    // 2^band_log2 feature rows of this level, in image pixels
-        k = ((uint64_t)lv4 << 52) | ((uint64_t)(band & 0xfffu) << 40) | ((uint64_t)xc << 20) | (uint32_t)r;
+        const uint32_t fs = min((uint32_t)p.k_min + lv4, 15u);                  // log2 feature stride
+        const uint32_t band = min((yc >> fs) >> p.band_log2, 63u), xf = min(xc >> fs, 4095u);
+        const uint32_t loc = (band << 12) | xf;                                   // 18 bits
+        k = ((uint64_t)lv4 << 52) | ((uint64_t)loc << 20) | (uint32_t)r;
       }
       keys[r] = k;
     }
     if (p.top_n <= 2048) {
       // rank by counting (keys are unique; n^2 compares, no barriers: beats 66 bitonic stages).  The order is only a
-      // locality hint, so the 64-bit key is squeezed into 32 bits -- level:3 | band:6 | x-centre/2:12 | rank:11 -- and each
+      // locality hint, so the 64-bit key is squeezed into 32 bits -- level:3 | locality code:18 | rank:11 -- and each
       // thread walks the table with 16-byte broadcast LDS reads (4 keys per ds_read_b128): 4x fewer LDS instructions than
       // one 8-byte read per compare, which is what bounded this phase (16 waves x 1000 reads on one CU = ~50 us).
       __syncthreads();
@@ -201,8 +205,8 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(Fpn
         const uint64_t k = keys[r];
         uint32_t c = 0xffffffffu;
         if (r < p.top_n) {
-          const uint32_t lv4 = (uint32_t)(k >> 52) & 0xfu, band = (uint32_t)(k >> 40) & 0xfffu, xc = (uint32_t)(k >> 20) & 0xffffu;
-          c = (min(lv4, 7u) << 29) | (min(band, 63u) << 23) | (min(xc >> 1, 4095u) << 11) | (uint32_t)r;
+          const uint32_t lv4 = (uint32_t)(k >> 52) & 0xfu, loc = (uint32_t)(k >> 20) & 0x3ffffu;
+          c = (min(lv4, 7u) << 29) | (loc << 11) | (uint32_t)r;
         }
         k32[r] = c;
       }
