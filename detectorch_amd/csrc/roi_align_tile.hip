@@ -51,6 +51,8 @@ enum { kGrpPool = 0, kGrpZero = 1, kGrpAbsent = 2, kGrpGather = 3 };
 // (rows of a level whose width is not a multiple of 4, P5's 42 columns, are read with the same instruction).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base) {
   // raw buffer, no bounds clamp (num_records = 2^32 - 1); word 3 = DATA_FORMAT 32 (the gfx9 raw-buffer encoding)
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000);
@@ -78,6 +80,22 @@ template <> struct Piece4<bf16_t> {
 };
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Development aid (-DDTC_TILE_TRACE, tools/r02/trace_tile.py): wave 0's cycle counter at the phase boundaries of a workgroup,
+// accumulated per phase and written to a global table.  Compiled out of the product.
+#ifdef DTC_TILE_TRACE
+constexpr int kTraceSlots = 16;
+__device__ unsigned long long g_tile_trace[kTraceSlots * 16384];
+struct TileTrace {
+  unsigned long long last, acc[kTraceSlots];
+  __device__ __forceinline__ void start() { for (int i = 0; i < kTraceSlots; i++) acc[i] = 0; last = __builtin_readcyclecounter(); }
+  __device__ __forceinline__ void mark(int i) { const unsigned long long n = __builtin_readcyclecounter(); acc[i] += n - last; last = n; }
+};
+#define TT_MARK(i) tt.mark(i)
+#else
+struct TileTrace {};
+#define TT_MARK(i) ((void)0)
+#endif
 
 // LDS slot (16-byte units: one pixel x 4 channels) of window pixel px inside one quad image: one pad slot every 8 pixels
 __device__ __forceinline__ int tile_phys(int px) { return px + (px >> 3); }
@@ -122,7 +140,7 @@ struct TileGeom {            // one cluster, all uniform
 template <typename TIn, typename TOut, int NT>
 __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_feat_level& L, const TIn* fbase, int c0, int nc,
                                             int bins, float* slab, float* win, const TileRoi* troi, const TileGeom& g,
-                                            const TileItem& it, int rl, int bin) {
+                                            const TileItem& it, int rl, int bin, TileTrace& tt) {
   constexpr int NW = NT / 64;
   constexpr int U = TileShape<NT>::kUnits;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, cl = (lane >> 4) & 3;
@@ -231,6 +249,7 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
     }
   };
 
+  TT_MARK(3);
   if (vec) issue(0);
   int cs_prev = 0, nq_prev = 0;
 #pragma unroll 1
@@ -238,49 +257,68 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
     const int cs = 4 * qs;
     const int nq_cur = min(nq_pass, nq_tot - qs);
     if (vec) commit(); else stage_scalar(cs);
+    TT_MARK(4);
     if (nq_prev) store_slab(cs_prev, nq_prev);
+    TT_MARK(5);
     __syncthreads();
+    TT_MARK(6);
     if (vec && qs + nq_pass < nq_tot) issue(cs + 4 * nq_pass);    // next pass: in flight (registers) while this one is pooled
+    TT_MARK(7);
     if (it.on) {
       float* so = slab + rl * (4 * nq_cur * bins) + bin;
 #pragma unroll 1
       for (int q = 0; q < nq_cur; q++) {
         // uniform quad offset, opaque to the optimiser: otherwise every tap address becomes its own induction variable
         const char* wq = reinterpret_cast<const char*>(win) + uni(q * plane * 16);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        // two channels per instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE results, twice the fp32 rate of the scalar forms)
+        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
         // reference order: for iy { for ix { acc += w1*v1 + w2*v2 + w3*v3 + w4*v4 } }   (roi_align_cpu_loop.cpp:203-214)
 #pragma unroll
         for (int iy = 0; iy < 2; iy++) {
-          float4 t[2][4];
+          f32x4 t[2][4];
 #pragma unroll
           for (int ix = 0; ix < 2; ix++)
 #pragma unroll
             for (int k = 0; k < 4; k++)                                       // 8 ds_read_b128 in flight per sample row
-              t[ix][k] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(wq + it.a[iy][ix][k], 16));
+              t[ix][k] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(wq + it.a[iy][ix][k], 16));
 #pragma unroll
           for (int ix = 0; ix < 2; ix++) {
             const float w1 = it.yh[iy] * it.xh[ix], w2 = it.yh[iy] * it.xl[ix];               // roi_align_cpu_loop.cpp:95
             const float w3 = it.yl[iy] * it.xh[ix], w4 = it.yl[iy] * it.xl[ix];
-            a0 += w1 * t[ix][0].x + w2 * t[ix][1].x + w3 * t[ix][2].x + w4 * t[ix][3].x;        // :208-211
-            a1 += w1 * t[ix][0].y + w2 * t[ix][1].y + w3 * t[ix][2].y + w4 * t[ix][3].y;
-            a2 += w1 * t[ix][0].z + w2 * t[ix][1].z + w3 * t[ix][2].z + w4 * t[ix][3].z;
-            a3 += w1 * t[ix][0].w + w2 * t[ix][1].w + w3 * t[ix][2].w + w4 * t[ix][3].w;
+            a01 += w1 * t[ix][0].lo + w2 * t[ix][1].lo + w3 * t[ix][2].lo + w4 * t[ix][3].lo;    // :208-211
+            a23 += w1 * t[ix][0].hi + w2 * t[ix][1].hi + w3 * t[ix][2].hi + w4 * t[ix][3].hi;
           }
           __builtin_amdgcn_sched_barrier(0);      // keep the two sample rows apart: 32, not 64, tap registers live
         }
         // :216  output_val /= count ; count == 4 -> x * 0.25f is the same float32
         float* o = so + uni(4 * q * bins);
+        const float a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
         o[0] = a0 * 0.25f; o[bins] = a1 * 0.25f; o[2 * bins] = a2 * 0.25f; o[3 * bins] = a3 * 0.25f;
       }
     }
+    TT_MARK(8);
     __syncthreads();
+    TT_MARK(9);
     cs_prev = cs; nq_prev = nq_cur;
   }
   if (nq_prev) store_slab(cs_prev, nq_prev);   // the next cluster writes the slab only behind its own first barrier
+  TT_MARK(10);
+}
+
+// Work item of block b: XCD x (= b % 8) owns a contiguous slice of the (cluster group, channel block) items, as in
+// xcd_work_item, but walks it BACK TO FRONT: the visiting order ends with the coarsest level of an image, whose RoIs have the
+// largest windows and merge least (3-4 clusters per workgroup, 2-2.5 x the average duration).  Started last they were the
+// tail of the launch (no workgroup starts during its last 20 %); started first the tail is made of average workgroups.
+__device__ __forceinline__ int tile_work_item(int b, int n, int reverse) {
+  if (n < 2 * kXcds) return reverse ? n - 1 - b : b;
+  const int x = b % kXcds, j = b / kXcds;
+  const int q = n / kXcds, r = n - q * kXcds;
+  const int start = x * q + min(x, r), qx = q + (x < r ? 1 : 0);
+  return start + (reverse ? qx - 1 - j : j);
 }
 
 template <typename TIn, typename TOut, int NT>
-__global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct) {
+__global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct, int reverse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileRoi* troi = reinterpret_cast<TileRoi*>(smem);
   TileGroup* tgrp = reinterpret_cast<TileGroup*>(smem + kTileMaxK * 32);
@@ -294,12 +332,17 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
   constexpr int kMaxPos = TileShape<NT>::kUnits * NW * 16;                  // 16-byte pieces the register pipeline can carry per quad
   const int tid = threadIdx.x;
   const int nct = ceil_div(p.channels, p.ch_block);
-  const int wi = xcd_work_item(blockIdx.x, gridDim.x, p.xcd_remap);
+  const int wi = tile_work_item(blockIdx.x, gridDim.x, reverse);
   const int grp = wi / nct;
   const int c0 = (wi - grp * nct) * p.ch_block;
   const int nc = min(p.ch_block, p.channels - c0);
   const int bins = p.pooled_h * p.pooled_w;
   const int K = kgroup;
+  TileTrace tt;
+#ifdef DTC_TILE_TRACE
+  tt.start();
+  const unsigned long long wall0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- A. windows of this workgroup's K RoIs (lane k) -----------------------------------------------------------------
   if (tid < K) {
@@ -322,6 +365,7 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
     troi[tid] = t;
   }
   __syncthreads();
+  TT_MARK(0);
 
   // ---- B. greedy clustering along the visiting order (one lane; K <= 32 steps) ----------------------------------------
   if (tid == 0) {
@@ -362,6 +406,7 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
     *ngp = ng;
   }
   __syncthreads();
+  TT_MARK(1);
 
   // ---- C. clusters ----------------------------------------------------------------------------------------------------
   const int ngroups = uni(*ngp);
@@ -448,9 +493,27 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
         asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));   // one finished VGPR per tap: do not re-derive in the loop
         it.a[iy][ix][0] = t0; it.a[iy][ix][1] = t1; it.a[iy][ix][2] = t2; it.a[iy][ix][3] = t3;
       }
-    tile_passes<TIn, TOut, NT>(p, L, fbase, c0, nc, bins, slab, win, troi, g, it, rl, bin);
+    TT_MARK(2);
+    tile_passes<TIn, TOut, NT>(p, L, fbase, c0, nc, bins, slab, win, troi, g, it, rl, bin, tt);
   }
+#ifdef DTC_TILE_TRACE
+  if (tid == 0 && blockIdx.x < 16384) {
+    unsigned long long* o = g_tile_trace + (size_t)blockIdx.x * kTraceSlots;
+    for (int i = 0; i < 11; i++) o[i] = tt.acc[i];
+    o[11] = wall0; o[12] = __builtin_amdgcn_s_memrealtime();
+    o[13] = (unsigned long long)ngroups; o[14] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    o[15] = (unsigned long long)wi;
+  }
+#endif
 }
+
+#ifdef DTC_TILE_TRACE
+}  // namespace dtc
+extern "C" __attribute__((visibility("default"))) int dtc_debug_tile_trace(void* host_dst, size_t bytes) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(dtc::g_tile_trace), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+namespace dtc {
+#endif
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
 struct TileConfig {
@@ -460,6 +523,7 @@ struct TileConfig {
   int ch_block = 0;    // channels per workgroup (0: chosen per launch)
   int merge_pct = 250; // a cluster may stage at most this % of the pixels its members would stage separately
   int nq_cap = 0;      // channel quads per pass, upper bound (0: 4) -- sizes the LDS output slab
+  int reverse = 1;     // walk an XCD's slice of the visiting order back to front (heaviest workgroups first)
 };
 static const TileConfig& tile_config() {   // development knobs, resolved ONCE (thread-safe static initialisation)
   static const TileConfig cfg = [] {
@@ -469,6 +533,7 @@ static const TileConfig& tile_config() {   // development knobs, resolved ONCE (
     if (const char* e = getenv("DTC_RA_TILE_K")) { const int v = atoi(e); if (v >= 1 && v <= kTileMaxK) c.k = v; }
     if (const char* e = getenv("DTC_RA_TILE_MERGE")) { const int v = atoi(e); if (v >= 100 && v <= 100000) c.merge_pct = v; }
     if (const char* e = getenv("DTC_RA_TILE_NQCAP")) { const int v = atoi(e); if (v >= 1 && v <= 8) c.nq_cap = v; }
+    if (const char* e = getenv("DTC_RA_TILE_REVERSE")) c.reverse = atoi(e) != 0;
     if (const char* e = getenv("DTC_RA_TILE_CHBLOCK")) { const int v = atoi(e); if (v >= 4 && (v & 3) == 0) c.ch_block = v; }
     return c;
   }();
@@ -500,7 +565,7 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   p.ch_block = cb;
   p.xcd_remap = 1;
   const int nct = ceil_div(p.channels, p.ch_block);
-  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct);
+  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, cfg.reverse ? 1 : 0);
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }
