@@ -27,12 +27,19 @@ __device__ __forceinline__ uint32_t desc_key_index(uint64_t k) { return (uint32_
 constexpr uint64_t kPadKey = ~0ull;
 
 // Sort keys[0..n_pow2) ascending.  n_pow2 is a power of two >= 2; every thread of the block must call.
+// Comparator t of a step belongs to thread t % THREADS.  For distances j <= 64 the 64 comparators of a wave touch exactly the
+// 128 consecutive keys [128 * (t / 64), +128) -- the same keys in every such step -- so consecutive steps with j <= 64 are
+// private to the wave: LDS executes a wave's accesses in order, no workgroup barrier is needed between them (a sort of 1024
+// keys has 55 steps, 9 of them with j >= 128).  A barrier separates steps only where the partition changes.
 template <int THREADS>
 __device__ __forceinline__ void block_bitonic_sort(uint64_t* keys, int n_pow2) {
   const int tid = threadIdx.x;
+  bool wide_prev = true;                                  // keys were written by arbitrary threads before the call
   for (int k = 2; k <= n_pow2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      __syncthreads();
+      const bool wide = j > 64;
+      if (wide || wide_prev) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+      wide_prev = wide;
       for (int t = tid; t < (n_pow2 >> 1); t += THREADS) {
         // t-th comparator of this stage: i has bit j clear
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));

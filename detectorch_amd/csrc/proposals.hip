@@ -1,19 +1,23 @@
 // A2 + A3 + A4  RPN proposal generation for gfx950: anchor enumeration, pre-NMS top-k, box decode, clip, min-size filter
-// for ALL images and ALL FPN levels of a batch, device resident (no D2H), in 5 launches.
+// for ALL images and ALL FPN levels of a batch, device resident (no D2H), in 5 launches (round 1: 6;
+// the third histogram pass over the score maps is gone).
 //
 // Replaces GenerateProposals.forward up to the NMS call (lib/model/generate_proposals.py:31-109), which per level and
 // per image does: numpy anchor meshgrid + H2D (:49-56,124-149), permute+contiguous of scores/deltas + 2 D2H (:64-73),
 // host argpartition/argsort (:77-86), ~25 tiny torch kernels for decode/clip (:96-100,165-238), D2H + host filter
 // (:101-109).
 //
-//   rpn_hist<0,1,2>   3-pass radix select (11+11+10 bits) of the K-th largest score per (image, level) segment; LDS
-//                     histograms, one global atomic per non-empty bin.  Scores are read once per pass in their native
-//                     conv layout [A,H,W] (coalesced); the (A,H,W)->(H,W,A) permute of :64,72 is only an index formula.
-//   rpn_compact       elements above the threshold key -> 64-bit (score desc, canonical index asc) keys; elements
-//                     EQUAL to it -> tie list (the canonical tie rule picks the lowest indices among them).
-//   rpn_sort_decode   one workgroup per segment: bitonic sort of the <= K candidates in LDS, then per rank: anchor =
-//                     f(index) from the A base anchors (never materialised, :124-149), decode (:165-214), clip
-//                     (:216-238), filter (:151-163), order-preserving compaction.
+//   rpn_hist<0,1>     2-pass radix histogram (12+12 bits of the order-preserving score key) locating the 24-bit bin that holds
+//                     the K-th largest score of every (image, level) segment; LDS histograms, one global atomic per non-empty
+//                     bin.  Scores are read in their native conv layout [A,H,W] (coalesced); the (A,H,W)->(H,W,A) permute
+//                     of :64,72 is only an index formula.
+//   rpn_compact       elements above that bin -> 64-bit (score desc, canonical index asc) keys that are certainly selected;
+//                     elements inside it (a few dozen at most, unless the map is constant) -> candidate keys.
+//   rpn_sort_decode   one workgroup per segment: bitonic sort of selected + candidate keys in LDS (the first K are the
+//                     answer, ties broken by the canonical index), then per rank: anchor = f(index) from the A base anchors
+//                     (never materialised, :124-149), decode (:165-214), clip (:216-238), filter (:151-163),
+//                     order-preserving compaction.  More candidates than the sort holds (constant / saturated maps): an
+//                     in-workgroup radix select over the candidate keys first.
 // Output per segment: boxes [K,4] + scores [K] in descending score order + count  == the `dets` handed to NMS at :115.
 #include "block_sort.h"
 #include "dtc_common.h"
@@ -23,7 +27,7 @@ namespace dtc {
 
 constexpr int kRpnMaxLevels = 8;
 constexpr int kRpnMaxAnchors = 16;
-constexpr int kHistBins = 2048;
+constexpr int kHistBins = 4096;   // 12 bits per pass
 constexpr int kHistThreads = 256;
 constexpr int kChunk = 4096;  // elements per workgroup in the streaming passes
 
@@ -43,10 +47,10 @@ struct RpnParams {
   RpnLevelDev lv[kRpnMaxLevels];
   int n_levels, batch, chunks_per_image, ties_per_image, k_stride;
   float im_h, im_w, min_size;
-  uint32_t* hist;       // [S][3][kHistBins]
-  uint32_t* counters;   // [S][2] : gt count, tie count
+  uint32_t* hist;       // [S][2][kHistBins]
+  uint32_t* counters;   // [S][2] : selected count, candidate count
   uint64_t* gt_keys;    // [S][k_stride]
-  uint32_t* tie_idx;    // [B][ties_per_image]
+  uint64_t* cand_keys;  // [B][ties_per_image]
   float* out_boxes;     // [S][k_stride][4]
   float* out_scores;    // [S][k_stride]
   int32_t* out_counts;  // [S]
@@ -61,43 +65,44 @@ __device__ __forceinline__ int find_level(const RpnParams& p, int chunk) {
 }
 
 // threshold state after `passes` completed passes: prefix (ordered-key bits found so far) and remaining rank
-struct SelState { uint32_t p0, p1, p2, krem; };
+struct SelState { uint32_t p0, p1, krem; };
 
 template <int PASSES>
 __device__ __forceinline__ SelState load_state(const RpnParams& p, int seg, uint32_t K, uint32_t* sh) {
-  SelState st; st.p0 = st.p1 = st.p2 = 0; st.krem = K;
-  const uint32_t* H = p.hist + (size_t)seg * 3 * kHistBins;
+  SelState st; st.p0 = st.p1 = 0; st.krem = K;
+  const uint32_t* H = p.hist + (size_t)seg * 2 * kHistBins;
   if (PASSES >= 1) { select_digit(H, kHistBins, st.krem, sh); st.p0 = sh[0]; st.krem = sh[1]; __syncthreads(); }
   if (PASSES >= 2) { select_digit(H + kHistBins, kHistBins, st.krem, sh); st.p1 = sh[0]; st.krem = sh[1]; __syncthreads(); }
-  if (PASSES >= 3) { select_digit(H + 2 * kHistBins, 1024, st.krem, sh); st.p2 = sh[0]; st.krem = sh[1]; __syncthreads(); }
   return st;
 }
 
 // ---- RPN-head epilogue fusion: scores handed over as LOGITS ----------------------------------------------
 // The reference ranks sigmoid(logit) (detector.py:125 -> generate_proposals.py:77-86).  sigmoid is monotone, so the radix
-// select runs on the raw logits untouched; but float32 sigmoid is many-to-one (every logit > 16.7 gives 1.0f), and equal
-// PROBABILITIES must tie-break by index exactly as if the probabilities had been materialised.  After the select has found
-// the K-th largest logit T, the band [lo, hi] of logits whose probability equals P* = sigmoid(T) is located by bisection on
-// the ordered keys (sigmoid evaluated in double and rounded once: the same value oracle/numpy produce): logits above the
-// band are certainly selected (their sort key carries their probability), logits inside it are the ties, the rest is out.
-// Only the K selected elements ever get a sigmoid evaluated -- the [B,A,H,W] probability map is never written or read.
+// histograms run on the raw logits untouched; but float32 sigmoid is many-to-one (every logit > 16.7 gives 1.0f), and equal
+// PROBABILITIES must tie-break by index exactly as if the probabilities had been materialised.  The K-th largest logit lies
+// in the key bin [bl, bh] the histograms found; every logit whose probability equals that of some logit of the bin could tie
+// with the K-th element, so the candidate band is widened to [lo, hi] with sigmoid(lo) == sigmoid(bl) and
+// sigmoid(hi) == sigmoid(bh) (two bisections on the ordered keys; sigmoid evaluated in double and rounded once: the same value
+// oracle / numpy produce).  Logits above hi have a strictly larger probability than the K-th element: certainly selected.
+// Only selected and candidate elements ever get a sigmoid -- the [B,A,H,W] probability map is never written or read.
 __device__ __forceinline__ float sigmoid_cr(float x) {
   return (float)(1.0 / (1.0 + exp(-(double)x)));
 }
-struct TieBand { uint32_t lo, hi; float p; };   // ordered-key band of the threshold score and the score itself
+struct KeyBand { uint32_t lo, hi; };   // ordered-key band of the candidates
 
-// one wave: lane 0 bisects upwards, lane 1 downwards; result broadcast through sh3[3].  Call from all threads of the block.
-__device__ __forceinline__ TieBand tie_band(uint32_t T, bool logit, uint32_t* sh3) {
-  TieBand tb;
-  if (!logit) { tb.lo = tb.hi = T; tb.p = ordered_to_float(T); return tb; }
+// lane 0 bisects downwards from bl, lane 1 upwards from bh; result broadcast through sh2[0..1].  Call from all threads.
+__device__ __forceinline__ KeyBand candidate_band(uint32_t bl, uint32_t bh, bool logit, uint32_t* sh2) {
+  KeyBand kb; kb.lo = bl; kb.hi = bh;
+  if (!logit) return kb;
+  const uint32_t kinf_p = float_to_ordered(__uint_as_float(0x7f800000u)), kinf_n = float_to_ordered(__uint_as_float(0xff800000u));
   __syncthreads();
   if (threadIdx.x < 2) {
-    const float pt = sigmoid_cr(ordered_to_float(T));
-    const uint32_t pk = float_to_ordered(pt);
-    const bool up = threadIdx.x == 0;
+    const bool up = threadIdx.x == 1;
+    // start inside the finite range (keys beyond +-inf are NaN patterns: never produced by a conv)
+    uint32_t a = up ? min(max(bh, kinf_n), kinf_p) : max(min(bl, kinf_p), kinf_n);
+    const uint32_t pk = float_to_ordered(sigmoid_cr(ordered_to_float(a)));
     // invariant: f(a) == pk, f(b) != pk (b is outside the band or the end of the finite range)
-    uint32_t a = T;
-    uint32_t b = up ? float_to_ordered(__uint_as_float(0x7f800000u)) : float_to_ordered(__uint_as_float(0xff800000u));
+    uint32_t b = up ? kinf_p : kinf_n;
     if (float_to_ordered(sigmoid_cr(ordered_to_float(b))) == pk) a = b;      // band reaches +-inf
     else {
       while ((up ? b - a : a - b) > 1u) {
@@ -105,13 +110,12 @@ __device__ __forceinline__ TieBand tie_band(uint32_t T, bool logit, uint32_t* sh
         if (float_to_ordered(sigmoid_cr(ordered_to_float(m))) == pk) a = m; else b = m;
       }
     }
-    sh3[up ? 1 : 0] = a;
-    if (up) sh3[2] = __float_as_uint(pt);
+    sh2[up ? 1 : 0] = up ? max(a, bh) : min(a, bl);
   }
   __syncthreads();
-  tb.lo = sh3[0]; tb.hi = sh3[1]; tb.p = __uint_as_float(sh3[2]);
+  kb.lo = sh2[0]; kb.hi = sh2[1];
   __syncthreads();
-  return tb;
+  return kb;
 }
 
 template <int PASS>
@@ -131,12 +135,11 @@ __global__ __launch_bounds__(kHistThreads) void rpn_hist_kernel(RpnParams p) {
   const int begin = chunk * kChunk, end = min(begin + kChunk, L.N);
   for (int i = begin + threadIdx.x; i < end; i += kHistThreads) {
     const uint32_t o = float_to_ordered(sc[i]);
-    if (PASS == 0) atomicAdd(&h[o >> 21], 1u);
-    if (PASS == 1) { if ((o >> 21) == st.p0) atomicAdd(&h[(o >> 10) & 2047u], 1u); }
-    if (PASS == 2) { if ((o >> 10) == ((st.p0 << 11) | st.p1)) atomicAdd(&h[o & 1023u], 1u); }
+    if (PASS == 0) atomicAdd(&h[o >> 20], 1u);
+    if (PASS == 1) { if ((o >> 20) == st.p0) atomicAdd(&h[(o >> 8) & 4095u], 1u); }
   }
   __syncthreads();
-  uint32_t* G = p.hist + ((size_t)seg * 3 + PASS) * kHistBins;
+  uint32_t* G = p.hist + ((size_t)seg * 2 + PASS) * kHistBins;
   for (int i = threadIdx.x; i < kHistBins; i += kHistThreads) {
     const uint32_t v = h[i];
     if (v) atomicAdd(&G[i], v);
@@ -144,13 +147,13 @@ __global__ __launch_bounds__(kHistThreads) void rpn_hist_kernel(RpnParams p) {
 }
 
 __global__ __launch_bounds__(kHistThreads) void rpn_compact_kernel(RpnParams p) {
-  // Selected elements are staged in LDS (LDS atomics hand out the slots) and the workgroup claims its output range with
-  // ONE global atomic per list: per-wave global atomics on a single counter per segment serialise at the L2
-  // (measured 64 us for 8 images before this change).
+  // Selected elements and candidates are staged in LDS (LDS atomics hand out the slots: selected from the front, candidates
+  // from the back of one array -- an element is at most one of the two) and the workgroup claims its output range with ONE
+  // global atomic per list: per-wave global atomics on a single counter per segment serialise at the L2 (measured 64 us
+  // for 8 images before this change).
   __shared__ uint32_t sh[2];
   __shared__ uint32_t lcnt[2], gbase[2];
-  __shared__ uint64_t gt_s[kChunk];
-  __shared__ uint32_t tie_s[kChunk];
+  __shared__ uint64_t stage[kChunk];
   const int b = blockIdx.y;
   const int l = find_level(p, blockIdx.x);
   const RpnLevelDev& L = p.lv[l];
@@ -158,11 +161,11 @@ __global__ __launch_bounds__(kHistThreads) void rpn_compact_kernel(RpnParams p) 
   const int chunk = blockIdx.x - L.chunk_begin;
   const bool take_all = L.K >= L.N;
   if (threadIdx.x < 2) lcnt[threadIdx.x] = 0;
-  __shared__ uint32_t sh3[3];
-  TieBand tb; tb.lo = tb.hi = 0; tb.p = 0.f;
+  KeyBand kb; kb.lo = kb.hi = 0;
   if (!take_all) {
-    const SelState st = load_state<3>(p, seg, (uint32_t)L.K, sh);
-    tb = tie_band((st.p0 << 21) | (st.p1 << 10) | st.p2, L.logit != 0, sh3);
+    const SelState st = load_state<2>(p, seg, (uint32_t)L.K, sh);
+    const uint32_t bl = ((st.p0 << 12) | st.p1) << 8;
+    kb = candidate_band(bl, bl | 0xffu, L.logit != 0, sh);
   }
   __syncthreads();
   const float* sc = L.cls + (size_t)b * L.N;
@@ -171,14 +174,15 @@ __global__ __launch_bounds__(kHistThreads) void rpn_compact_kernel(RpnParams p) 
   for (int i = begin + threadIdx.x; i < end; i += kHistThreads) {
     const float s = sc[i];
     const uint32_t o = float_to_ordered(s);
-    const bool is_gt = take_all || o > tb.hi;
-    const bool is_tie = !take_all && o >= tb.lo && o <= tb.hi;
-    if (is_gt || is_tie) {
+    const bool is_gt = take_all || o > kb.hi;
+    const bool is_cand = !take_all && o >= kb.lo && o <= kb.hi;
+    if (is_gt || is_cand) {
       // memory index i = (a*H + h)*W + w  ->  canonical index n = (h*W + w)*A + a   (generate_proposals.py:64,72)
       const int a = i / HW, hw = i - a * HW;
       const uint32_t n = (uint32_t)(hw * L.A + a);
-      if (is_gt) gt_s[atomicAdd(&lcnt[0], 1u)] = make_desc_key(L.logit ? sigmoid_cr(s) : s, n);
-      else tie_s[atomicAdd(&lcnt[1], 1u)] = n;
+      const uint64_t key = make_desc_key(L.logit ? sigmoid_cr(s) : s, n);
+      if (is_gt) stage[atomicAdd(&lcnt[0], 1u)] = key;
+      else stage[kChunk - 1 - atomicAdd(&lcnt[1], 1u)] = key;
     }
   }
   __syncthreads();
@@ -186,10 +190,10 @@ __global__ __launch_bounds__(kHistThreads) void rpn_compact_kernel(RpnParams p) 
   if (threadIdx.x < 2) gbase[threadIdx.x] = lcnt[threadIdx.x] ? atomicAdd(&cnt[threadIdx.x], lcnt[threadIdx.x]) : 0u;
   __syncthreads();
   uint64_t* gt = p.gt_keys + (size_t)seg * p.k_stride;
-  uint32_t* tie = p.tie_idx + (size_t)b * p.ties_per_image + L.tie_begin;
+  uint64_t* cand = p.cand_keys + (size_t)b * p.ties_per_image + L.tie_begin;
   for (uint32_t j = threadIdx.x; j < lcnt[0]; j += kHistThreads)
-    if (gbase[0] + j < (uint32_t)p.k_stride) gt[gbase[0] + j] = gt_s[j];
-  for (uint32_t j = threadIdx.x; j < lcnt[1]; j += kHistThreads) tie[gbase[1] + j] = tie_s[j];
+    if (gbase[0] + j < (uint32_t)p.k_stride) gt[gbase[0] + j] = stage[j];
+  for (uint32_t j = threadIdx.x; j < lcnt[1]; j += kHistThreads) cand[gbase[1] + j] = stage[kChunk - 1 - j];
 }
 
 // generate_proposals.py:165-214 (weights (1,1,1,1)) + :216-238 + :151-163
@@ -209,11 +213,23 @@ __device__ __forceinline__ void decode_box(float ax1, float ay1, float ax2, floa
 
 constexpr int kSortDecodeThreads = 1024;
 
+// Ascending digit select inside the workgroup: smallest digit d with  count(digits <= d) >= rem.  hist[nbins] in LDS,
+// nbins <= 2048.  Returns d in sh[0] and the rank left inside digit d in sh[1].  (select_digit picks from the top: feed
+// it the mirrored histogram.)
+__device__ __forceinline__ void select_digit_asc(uint32_t* hist, int nbins, uint32_t rem, uint32_t* sh) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < nbins / 2; i += blockDim.x) { const uint32_t t = hist[i]; hist[i] = hist[nbins - 1 - i]; hist[nbins - 1 - i] = t; }
+  __syncthreads();
+  select_digit(hist, nbins, rem, sh);
+  if (threadIdx.x == 0) sh[0] = (uint32_t)(nbins - 1) - sh[0];
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_decode_kernel(RpnParams p, int sort_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
   __shared__ uint32_t sh[2];
-  __shared__ uint32_t hidx[512];
+  __shared__ uint32_t hsel[2048];
   __shared__ int wave_tot[kSortDecodeThreads / 64];
   __shared__ int running;
   const int seg = blockIdx.x;
@@ -221,56 +237,56 @@ __global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_decode_kernel(Rpn
   const RpnLevelDev& L = p.lv[l];
   const int tid = threadIdx.x;
   const uint32_t n_gt = min(p.counters[(size_t)seg * 2], (uint32_t)p.k_stride);
-  const uint32_t n_tie = p.counters[(size_t)seg * 2 + 1];
+  const uint32_t n_cand = p.counters[(size_t)seg * 2 + 1];
   const uint64_t* gt = p.gt_keys + (size_t)seg * p.k_stride;
-  const uint32_t* tie = p.tie_idx + (size_t)b * p.ties_per_image + L.tie_begin;
+  const uint64_t* cand = p.cand_keys + (size_t)b * p.ties_per_image + L.tie_begin;
   const int K = L.K;
-  const uint32_t need = (uint32_t)K - n_gt;  // ties to take (0 when take_all)
-  float tie_score = 0.f;
-  if (n_tie) {  // all ties share the threshold score: recover it from the selection state
-    const SelState st = load_state<3>(p, seg, (uint32_t)K, sh);
-    tie_score = ordered_to_float((st.p0 << 21) | (st.p1 << 10) | st.p2);
-    if (L.logit) tie_score = sigmoid_cr(tie_score);     // == TieBand::p of the compaction pass
-  }
-  uint32_t idx_limit = 0xffffffffu;  // ties with canonical index <= idx_limit are taken
-  uint32_t n_take = n_tie;
-  if (n_gt + n_tie > (uint32_t)sort_cap) {
-    // Massive tie at the threshold (e.g. a constant score map): pick the `need` lowest canonical indices with a
-    // 2 x 9-bit radix select over the tie list (indices < 2^18 would suffice for FPN; 3 passes cover 2^27).
-    uint32_t prefix = 0, rem = need;
-    for (int pass = 0; pass < 3; pass++) {
-      const int shift = 18 - 9 * pass;
-      for (int i = tid; i < 512; i += kSortDecodeThreads) hidx[i] = 0;
+  const uint32_t need = (uint32_t)K - n_gt;  // candidates to take (0 when everything is taken)
+  // More candidates than the sort holds (a constant map, a saturated sigmoid): the `need` smallest candidate keys are found
+  // with a radix select over (a) the 32 score bits, (b) the canonical index among the candidates that share the threshold
+  // score.  Not a fast path: it re-reads the candidate list once per digit.
+  bool filtered = false;
+  uint32_t u_star = 0, idx_limit = 0xffffffffu;
+  if (n_gt + n_cand > (uint32_t)sort_cap) {
+    filtered = true;
+    uint32_t rem = need;
+    uint64_t prefix = 0;       // bits of the key above the digit being resolved
+    for (int pass = 0; pass < 6; pass++) {
+      // digits: key bits [63:53] [52:42] [41:32] | [26:18] [17:9] [8:0]   (bits [31:27] of an index are zero: N < 2^27)
+      const int shift = pass == 0 ? 53 : pass == 1 ? 42 : pass == 2 ? 32 : pass == 3 ? 18 : pass == 4 ? 9 : 0;
+      const int bits = pass < 2 ? 11 : pass == 2 ? 10 : 9;
+      const int hi_shift = pass == 3 ? 32 : shift + bits;        // the first index digit sits right below the score word
+      const int nb = 1 << bits;
+      for (int i = tid; i < nb; i += kSortDecodeThreads) hsel[i] = 0;
       __syncthreads();
-      for (uint32_t i = tid; i < n_tie; i += kSortDecodeThreads) {
-        const uint32_t v = tie[i];
-        if (pass == 0 || (v >> (shift + 9)) == prefix) atomicAdd(&hidx[(v >> shift) & 511u], 1u);
+      for (uint32_t i = tid; i < n_cand; i += kSortDecodeThreads) {
+        const uint64_t v = cand[i];
+        if (pass == 0 || (v >> hi_shift) == prefix) atomicAdd(&hsel[(uint32_t)(v >> shift) & (uint32_t)(nb - 1)], 1u);
       }
-      __syncthreads();
-      if (tid == 0) {  // ascending select: smallest d with cumulative >= rem
-        uint32_t acc = 0; int d = 0;
-        for (d = 0; d < 512; d++) { if (acc + hidx[d] >= rem) break; acc += hidx[d]; }
-        sh[0] = (uint32_t)d; sh[1] = rem - acc;
-      }
-      __syncthreads();
-      prefix = (prefix << 9) | sh[0]; rem = sh[1];
+      select_digit_asc(hsel, nb, rem, sh);
+      const uint32_t d = sh[0];
+      rem = sh[1];
+      prefix = pass == 3 ? (prefix << 14) | d : (prefix << bits) | d;   // pass 3: 5 zero bits + 9 digit bits below the score word
       __syncthreads();
     }
-    idx_limit = prefix;
-    n_take = need;
+    // prefix is now the complete key of the last candidate taken
+    u_star = (uint32_t)(prefix >> 32);
+    idx_limit = (uint32_t)prefix;
   }
-  // gather candidates into LDS.  Ties are appended through an LDS cursor when filtered by idx_limit.
+  // gather into LDS: selected keys, then the candidates (all of them, or the filtered `need`)
+  const uint32_t n_take = filtered ? need : n_cand;
   const int total = (int)(n_gt + n_take);
   const int np2 = next_pow2(total);
   for (int i = tid; i < np2; i += kSortDecodeThreads) keys[i] = i < (int)n_gt ? gt[i] : kPadKey;
   if (tid == 0) running = (int)n_gt;
   __syncthreads();
-  if (idx_limit == 0xffffffffu) {
-    for (uint32_t i = tid; i < n_tie; i += kSortDecodeThreads) keys[n_gt + i] = make_desc_key(tie_score, tie[i]);
+  if (!filtered) {
+    for (uint32_t i = tid; i < n_cand; i += kSortDecodeThreads) keys[n_gt + i] = cand[i];
   } else {
-    for (uint32_t i = tid; i < n_tie; i += kSortDecodeThreads) {
-      const uint32_t v = tie[i];
-      if (v <= idx_limit) { const int slot = atomicAdd(&running, 1); if (slot < np2) keys[slot] = make_desc_key(tie_score, v); }
+    const uint64_t last = ((uint64_t)u_star << 32) | idx_limit;
+    for (uint32_t i = tid; i < n_cand; i += kSortDecodeThreads) {
+      const uint64_t v = cand[i];
+      if (v <= last) { const int slot = atomicAdd(&running, 1); if (slot < np2) keys[slot] = v; }
     }
   }
   __syncthreads();
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_decode_kernel(Rpn
       const uint32_t n = desc_key_index(keys[k]);
       const int a = n % L.A, hw = n / L.A;
       const int h = hw / L.W, w = hw - h * L.W;
-      s = L.logit ? desc_key_score(keys[k]) : sc[(size_t)a * HW + hw];
+      s = L.logit ? desc_key_score(keys[k]) : sc[(size_t)a * HW + hw];   // the key carries the probability
       // :124-149 shifted anchor: float64 add of exactly representable values, rounded to float32 (:54) -> exact
       const float sx = (float)w * L.feat_stride, sy = (float)h * L.feat_stride;
       const float ax1 = L.anchors[a * 4 + 0] + sx, ay1 = L.anchors[a * 4 + 1] + sy;
@@ -371,10 +387,10 @@ static int make_plan(const dtc_rpn_level* levels, int n_levels, int batch, int k
   const int S = batch * n_levels;
   plan->chunks_per_image = chunks; plan->ties_per_image = ties; plan->k_stride = k_stride; plan->n_seg = S;
   size_t o = 0;
-  plan->off_hist = o; o += al((size_t)S * 3 * kHistBins * sizeof(uint32_t));
+  plan->off_hist = o; o += al((size_t)S * 2 * kHistBins * sizeof(uint32_t));
   plan->off_counters = o; o += al((size_t)S * 2 * sizeof(uint32_t));
   plan->off_gt = o; o += al((size_t)S * k_stride * sizeof(uint64_t));
-  plan->off_tie = o; o += al((size_t)batch * ties * sizeof(uint32_t));
+  plan->off_tie = o; o += al((size_t)batch * ties * sizeof(uint64_t));
   plan->total = o;
   return DTC_OK;
 }
@@ -404,7 +420,7 @@ DTC_API int dtc_rpn_topk_decode(const dtc_rpn_level* levels, int n_levels, int b
   p.hist = reinterpret_cast<uint32_t*>(w + plan.off_hist);
   p.counters = reinterpret_cast<uint32_t*>(w + plan.off_counters);
   p.gt_keys = reinterpret_cast<uint64_t*>(w + plan.off_gt);
-  p.tie_idx = reinterpret_cast<uint32_t*>(w + plan.off_tie);
+  p.cand_keys = reinterpret_cast<uint64_t*>(w + plan.off_tie);
   p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_counts = out_counts;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // histograms + counters are contiguous at the start of the workspace
@@ -412,7 +428,6 @@ DTC_API int dtc_rpn_topk_decode(const dtc_rpn_level* levels, int n_levels, int b
   const dim3 grid(plan.chunks_per_image, batch), blk(dtc::kHistThreads);
   hipLaunchKernelGGL(dtc::rpn_hist_kernel<0>, grid, blk, 0, s, p);
   hipLaunchKernelGGL(dtc::rpn_hist_kernel<1>, grid, blk, 0, s, p);
-  hipLaunchKernelGGL(dtc::rpn_hist_kernel<2>, grid, blk, 0, s, p);
   hipLaunchKernelGGL(dtc::rpn_compact_kernel, grid, blk, 0, s, p);
   DTC_CHECK_LAUNCH();
   const int sort_cap = dtc::next_pow2(plan.k_stride) <= 1024 ? 2048 : dtc::next_pow2(plan.k_stride);

@@ -6,15 +6,15 @@
 namespace dtc {
 
 // Wave 0 of the block: find the digit d with  sum(h[d+1..]) < k <= sum(h[d..])  and the remaining rank inside it.
-// Result broadcast through sh[0..1].  nbins <= 2048.
+// Result broadcast through sh[0..1].  nbins <= 4096, a multiple of 64.
 __device__ __forceinline__ void select_digit(const uint32_t* __restrict__ h, int nbins, uint32_t k, uint32_t* sh) {
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     const int per = nbins / 64;
-    uint32_t local[32];
+    uint32_t local[64];
     uint32_t tot = 0;
 #pragma unroll
-    for (int i = 0; i < 32; i++) {
+    for (int i = 0; i < 64; i++) {
       local[i] = i < per ? h[lane * per + i] : 0u;
       tot += local[i];
     }
@@ -32,7 +32,7 @@ __device__ __forceinline__ void select_digit(const uint32_t* __restrict__ h, int
       uint32_t rem = 0;
       bool found = false;
 #pragma unroll
-      for (int i = 31; i >= 0; i--) {
+      for (int i = 63; i >= 0; i--) {
         if (i < per && !found) {
           if (acc + local[i] >= k) { d = lane * per + i; rem = k - acc; found = true; }
           acc += local[i];

@@ -129,5 +129,12 @@ def test_forward_batched_batch2_and_bf16_head():
     model._paths.clear()
     pb = model.forward_batched(images[:1], sf[:1], im_size[:1])
     assert pb.box_feats.dtype == torch.bfloat16
-    err = (pb.cls_logits_out - ref_logits).abs().max() / ref_logits.abs().max()
+    # rows are RoIs in proposal order; the conv outputs of two calls can differ in the last bits and swap near-tied proposals,
+    # so match the RoIs of the two runs by their boxes before comparing the head outputs row by row
+    nb = int(pb.n_rois[0])
+    d = (pb.rois5[0, :nb, 1:][:, None, :] - p1.rois5[0, :n2[0], 1:][None, :, :]).abs().amax(2)
+    dmin, j = d.min(1)
+    ok = dmin < 1e-3
+    assert float(ok.float().mean()) > 0.9
+    err = (pb.cls_logits_out[0, :nb][ok] - ref_logits[0][j[ok]]).abs().max() / ref_logits.abs().max()
     assert float(err) < 5e-2
