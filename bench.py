@@ -26,6 +26,7 @@ Workloads (BASELINE.json configs):
 Prints ONE JSON line on rank 0 (fields: the task contract + `roofline` + `cpu_baseline` + `consistency`).
 """
 import argparse
+import contextlib
 import json
 import os
 import socket
@@ -57,6 +58,7 @@ def parse():
     ap.add_argument("--cpu-images", type=int, default=8, help="images of the same workload run on the CPU oracle (timed + compared with the GPU)")
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--sustain-seconds", type=float, default=1.0, help="extra untimed-by-contract run of at least this long, reported under `consistency`")
+    ap.add_argument("--inflight", type=int, default=2, help="steps in flight: consecutive steps (independent batches) are issued round-robin on this many HIP streams, so the latency-bound kernels of one step overlap the RoIAlign launches of another")
     ap.add_argument("--split", type=int, default=1, help="sub-batches run on separate HIP streams inside one hipGraph (cfg3/cfg5)")
     return ap.parse_args()
 
@@ -217,13 +219,14 @@ def main():
         assert world == a.gpus, (world, a.gpus)
 
     from detectorch_amd import hip
-    from detectorch_amd.pipeline import C4RegionPath, FpnRegionPath, OverlappedRegionPath, synthetic_batch, synthetic_c4_batch
+    from detectorch_amd.pipeline import (C4RegionPath, FpnRegionPath, OverlappedRegionPath, StepPipeline, synthetic_batch,
+                                         synthetic_c4_batch)
     hip.lib()   # fails loudly if the native library is missing
     wl = a.workload
     fp16 = a.fp16 or wl == "cfg5"
     fdt = torch.float16 if fp16 else torch.float32
     top_n = 2000 if wl == "cfg5" else 1000
-    NSETS = 2
+    NSETS = max(2, a.inflight)
     paths, inputs = [], []
     for s in range(NSETS):
         seed = {"cfg3": 3000, "cfg5": 5000, "cfg2": 2000}[wl] + 500 * s + rank
@@ -245,14 +248,13 @@ def main():
         from detectorch_amd.dist import DetectionGatherer
         gather = DetectionGatherer(paths[0].B, paths[0].max_out, dev, world)
 
-    counter = [0]
+    pipe = StepPipeline(paths, dev, n_inflight=a.inflight)
 
     def one_step():
-        p = paths[counter[0] % NSETS]
-        counter[0] += 1
-        p.step(use_graph=not a.eager)
+        p, st = pipe.step(use_graph=not a.eager)                  # step k+1 is issued while step k runs (StepPipeline)
         if gather is not None:
-            gather.all_gather_async(p.dets, p.det_count)      # one packed collective per step, overlapped with the next
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                gather.all_gather_async(p.dets, p.det_count)      # one packed collective per step, overlapped with the next
 
     def timed(n_steps):
         torch.cuda.synchronize(dev)
@@ -279,7 +281,7 @@ def main():
         one_step()
     if gather is not None:
         gather.finish()
-    counter[0] = 0
+    pipe.count = 0
     dt = timed(a.steps)                      # the contract: exactly K steps, barrier + synchronize on both sides, max over ranks
     # a longer run of the same loop (>= --sustain-seconds): the contract region is only K steps long
     n_sus = int(max(a.steps, np.ceil(a.sustain_seconds / max(dt / a.steps, 1e-6)))) if a.sustain_seconds > 0 else 0
@@ -339,7 +341,9 @@ def main():
                        "images_per_gpu_per_step": a.batch, "global_batch": a.batch * world, "rois_per_image": top_n,
                        "input_sets_rotated": NSETS,
                        "feature_layout": "NHWC" if a.channels_last else "NCHW",
-                       "launch": ("eager" if a.eager else "hipGraph") + (", %d sub-batches on %d streams" % (a.split, a.split) if isinstance(p0, OverlappedRegionPath) else ""),
+                       "launch": ("eager" if a.eager else "hipGraph") + (", %d sub-batches on %d streams" % (a.split, a.split) if isinstance(p0, OverlappedRegionPath) else "") +
+                                 (", %d steps in flight on %d HIP streams (StepPipeline)" % (a.inflight, a.inflight) if a.inflight > 1 else ""),
+                       "steps_in_flight": a.inflight,
                        "parallelism": "images sharded over %d GPU(s); all_gather of detections" % world,
                        "not_in_path": not_in},
             "roofline": {"bound": "hbm", "kernel": kern,

@@ -77,6 +77,35 @@ def test_overlapped_split_equals_single(oracle):
         assert torch.equal(one.dets[b, :n], two.dets[b, :n])
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_steps_in_flight_equal_steps_alone(oracle, use_graph):
+    """StepPipeline: consecutive steps on two HIP streams (their kernels interleave on the device) leave exactly the results
+    every path produces when it runs alone -- proposals, pooled features, detections, crops."""
+    from detectorch_amd.pipeline import FpnRegionPath, StepPipeline, synthetic_batch
+    dev = torch.device("cuda", 0)
+    B, C = 2, 16
+    paths, want = [], []
+    for s in range(2):
+        p = FpnRegionPath(B, dev, channels=C)
+        p.bind(*synthetic_batch(B, dev, seed=3300 + 17 * s, channels=C))
+        p.crops.zero_()                      # capacity buffer: only the pasted rectangles are written
+        p.step(use_graph=False)
+        torch.cuda.synchronize()
+        want.append([t.clone() for t in (p.rois5, p.n_rois, p.box_feats, p.dets, p.det_count, p.mask_feats, p.crops)])
+        for t in (p.rois5, p.box_feats, p.dets, p.mask_feats, p.crops):
+            t.zero_()
+        paths.append(p)
+    pipe = StepPipeline(paths, dev, n_inflight=2)
+    for _ in range(7):
+        pipe.step(use_graph=use_graph)
+    pipe.synchronize()
+    torch.cuda.synchronize()
+    for p, w in zip(paths, want):
+        got = (p.rois5, p.n_rois, p.box_feats, p.dets, p.det_count, p.mask_feats, p.crops)
+        for g, e in zip(got, w):
+            assert torch.equal(g, e)
+
+
 def test_bench_configuration_vs_oracle_chain(oracle):
     """The exact configuration bench.py times -- seed 3000, batch 8, C = 256, hipGraph replay -- against the oracle chain for
     the first and the last image of the batch (every intermediate bit-exact, incl. the 8000-RoI box-head RoIAlign launch)."""
