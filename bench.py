@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--fp16", action="store_true", help="fp16 feature maps / pooled features (cfg5 sets this itself)")
     ap.add_argument("--c4-pooled", type=int, default=7, help="cfg2: pooled size (7 as BASELINE names it; 14 = the reference's C4 default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-always", action="store_true", help="run the per-step RCCL all-gather of the detections even at world size 1 (tests: exercises the N > 1 code path on one GPU; needs a launcher environment)")
     ap.add_argument("--cpu-images", type=int, default=8, help="images of the same workload run on the CPU oracle (timed + compared with the GPU)")
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--sustain-seconds", type=float, default=1.0, help="extra untimed-by-contract run of at least this long, reported under `consistency`")
@@ -211,7 +212,7 @@ def main():
     dev = torch.device("cuda", local)
     dist = None
     world = 1
-    if world_env > 1:
+    if world_env > 1 or (a.gather_always and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world_env, device_id=dev)
@@ -244,7 +245,7 @@ def main():
         paths.append(p)
         inputs.append(inp)
     gather = None
-    if world > 1:
+    if world > 1 or (a.gather_always and dist is not None):
         from detectorch_amd.dist import DetectionGatherer
         gather = DetectionGatherer(paths[0].B, paths[0].max_out, dev, world)
 
@@ -283,6 +284,13 @@ def main():
         gather.finish()
     pipe.count = 0
     dt = timed(a.steps)                      # the contract: exactly K steps, barrier + synchronize on both sides, max over ranks
+    gathered_ok = None
+    if gather is not None:                   # what every rank received for THIS rank's last step == what the path holds
+        gd, gc = gather.finish()
+        pl = paths[(a.steps - 1) % NSETS]
+        gathered_ok = bool(torch.equal(gd[rank], pl.dets) and torch.equal(gc[rank], pl.det_count))
+        if not gathered_ok:
+            raise SystemExit("all-gathered detections differ from the local result")
     # a longer run of the same loop (>= --sustain-seconds): the contract region is only K steps long
     n_sus = int(max(a.steps, np.ceil(a.sustain_seconds / max(dt / a.steps, 1e-6)))) if a.sustain_seconds > 0 else 0
     if dist is not None and n_sus:
@@ -350,7 +358,7 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k_ms, 4)},
-            "consistency": {"timed_region_s": round(dt, 4),
+            "consistency": {"timed_region_s": round(dt, 4), "gathered_equals_local": gathered_ok,
                             "sustained": None if dt_sus is None else {"steps": n_sus, "seconds": round(dt_sus, 3),
                                                                       "ms_per_step": round(dt_sus / n_sus * 1e3, 4),
                                                                       "images_per_sec": round(a.batch * n_sus * world / dt_sus, 2)}},

@@ -63,3 +63,21 @@ def test_bench_refuses_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
                        text=True, timeout=600, env=env)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bench_gather_path_with_steps_in_flight_world1():
+    """The N > 1 bench loop on one GPU: world-size-1 RCCL group, the per-step packed all-gather issued from the two streams
+    the steps in flight run on; every gathered row must equal what the path produced (bench.py asserts that itself)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "4",
+                        "--sustain-seconds", "0", "--no-cpu-baseline", "--gather-always", "--inflight", "2"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["steps_in_flight"] == 2 and out["consistency"]["gathered_equals_local"] is True
