@@ -158,6 +158,7 @@ struct StagerNCHW {
       if (px >= ww) { px -= ww; py++; }
     }
   }
+  __device__ __forceinline__ void init_window(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int cts) { init(L, y0, x0, ww, wh, wh * ww, cts); }
   // full sub-tile (all cts channels valid)
   __device__ __forceinline__ void issue(const TIn* cbase, int cts, int nvalid) {
     const char* cb = reinterpret_cast<const char*>(cbase);
@@ -222,6 +223,7 @@ struct StagerNCHW2 {
   int cl, nk, ctp;
   int64_t stride_c;
   // (x0, ww) already widened to even columns; wwp = ww / 2 pairs per row
+  __device__ __forceinline__ void init_window(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int cts) { init(L, y0, x0, ww, wh, cts); }
   __device__ __forceinline__ void init(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int cts) {
     const int tid = threadIdx.x;
     const int pl = tid & 15, wv = tid >> 6;
@@ -287,6 +289,7 @@ struct StagerNHWC {
     return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
   }
   static __device__ __forceinline__ float4 load4(const bf16_t* p) { return bf16x4_to_f32(*reinterpret_cast<const uint2*>(p)); }
+  __device__ __forceinline__ void init_window(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int cts) { init(L, y0, x0, ww, wh, wh * ww, cts); }
   __device__ __forceinline__ void init(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int npix, int cts) {
     const int quads = cts >> 2;
     cq = threadIdx.x % quads;
@@ -337,11 +340,15 @@ struct LdsGeom {
   const LdsAxis* ytab; const LdsAxis* xtab;
   float* slab; float* win;
   int cts, bins, gh, gw, pooled_w, nc;
+  int bin0, nb;             // bins [bin0, bin0 + nb) are pooled from the staged window (all of them unless a large RoI is split)
+  // bin-row slices of a RoI whose window does not fit LDS at once: `rows` bin rows per slice (== pooled_h: one slice)
+  int rows, pooled_h, x0, ww, y0, wh, height;
+  float sh, bin_h;
   float count, inv_count;   // inv_count != 0 when count is a power of two (x * inv_count == x / count exactly)
 };
 
-template <typename TIn, typename TOut, typename Stager>
-__device__ __forceinline__ void run_passes(Stager& st, const LdsGeom& G, const TIn* fbase0, int64_t stride_c, TOut* out) {
+template <typename TIn, typename TOut, bool SLICED, typename Stager>
+__device__ __forceinline__ void run_passes(Stager& st, LdsGeom& G, const dtc_feat_level& L, const TIn* fbase0, int64_t stride_c, TOut* out) {
   const int tid = threadIdx.x;
   const int quads = G.cts >> 2;
   // ds_read_b128 is serviced in four 16-lane groups {0-3,12-15,20-27} {4-11,16-19,28-31} (+32): number the lanes group by
@@ -352,6 +359,19 @@ __device__ __forceinline__ void run_passes(Stager& st, const LdsGeom& G, const T
   const int vt = (tid & ~63) | (ln & 32) | (grp << 4) | ((ln >> 3) & 3) << 2 | (ln & 3);
   const int cq = vt % quads, slot = vt / quads, nslot = kRoiAlignThreads / quads;
   const float* wq = G.win + cq * 4;
+  // SLICED: the RoI is pooled in slices of G.rows bin rows, each with its own window (the kernel's comment); otherwise one
+  // iteration over the whole RoI (compile-time: the common path carries no slice state)
+#pragma unroll 1
+ for (int ph0 = 0; ph0 < (SLICED ? G.pooled_h : 1); ph0 += (SLICED ? G.rows : 1)) {
+  int yg = G.y0, whg = G.wh;
+  if constexpr (SLICED) {
+    const int ph1 = min(G.pooled_h, ph0 + G.rows);
+    // window rows of this slice: first sample of bin row ph0 .. last sample of bin row ph1 - 1 (the table values, recomputed)
+    yg = make_axis(G.sh, G.bin_h, ph0, 0, G.gh, G.height).lo;
+    whg = make_axis(G.sh, G.bin_h, ph1 - 1, G.gh - 1, G.gh, G.height).hi - yg + 1;
+    G.bin0 = ph0 * G.pooled_w; G.nb = (ph1 - ph0) * G.pooled_w;
+  }
+  st.init_window(L, yg, G.x0, G.ww, whg, G.cts);
   st.issue(fbase0, G.cts, min(G.cts, G.nc));
   for (int cs = 0; cs < G.nc; cs += G.cts) {
     const int nvalid = min(G.cts, G.nc - cs);
@@ -359,7 +379,8 @@ __device__ __forceinline__ void run_passes(Stager& st, const LdsGeom& G, const T
     __syncthreads();
     if (cs + G.cts < G.nc)  // prefetch the next channel sub-tile into registers; lands while this one is computed
       st.issue(fbase0 + (int64_t)(cs + G.cts) * stride_c, G.cts, min(G.cts, G.nc - cs - G.cts));
-    for (int bin = slot; bin < G.bins; bin += nslot) {
+    for (int lb = slot; lb < G.nb; lb += nslot) {
+      const int bin = G.bin0 + lb;
       const int ph = bin / G.pooled_w, pw = bin - ph * G.pooled_w;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       // reference order: for iy { for ix { acc += ... } }   (roi_align_cpu_loop.cpp:203-214)
@@ -378,18 +399,23 @@ __device__ __forceinline__ void run_passes(Stager& st, const LdsGeom& G, const T
           a3 += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
         }
       }
-      float* so = G.slab + (cq * 4) * G.bins + bin;
+      float* so = G.slab + (cq * 4) * G.nb + lb;
       if (G.inv_count != 0.f) {                                                               // :216
-        so[0] = a0 * G.inv_count; so[G.bins] = a1 * G.inv_count; so[2 * G.bins] = a2 * G.inv_count; so[3 * G.bins] = a3 * G.inv_count;
+        so[0] = a0 * G.inv_count; so[G.nb] = a1 * G.inv_count; so[2 * G.nb] = a2 * G.inv_count; so[3 * G.nb] = a3 * G.inv_count;
       } else {
-        so[0] = fdiv(a0, G.count); so[G.bins] = fdiv(a1, G.count); so[2 * G.bins] = fdiv(a2, G.count); so[3 * G.bins] = fdiv(a3, G.count);
+        so[0] = fdiv(a0, G.count); so[G.nb] = fdiv(a1, G.count); so[2 * G.nb] = fdiv(a2, G.count); so[3 * G.nb] = fdiv(a3, G.count);
       }
     }
     __syncthreads();
-    // coalesced store of the [nvalid][bins] slab
+    // coalesced store of the [nvalid][nb] slab
     TOut* og = out + (size_t)cs * G.bins;
-    const int n_out = nvalid * G.bins;
-    if (sizeof(TOut) == 4 && ((reinterpret_cast<uintptr_t>(og) & 15) == 0)) {
+    const int n_out = nvalid * G.nb;
+    if (G.nb != G.bins) {            // bin-row group of a split RoI: runs of nb consecutive bins per channel
+      for (int i = tid; i < n_out; i += kRoiAlignThreads) {
+        const int c = i / G.nb, j = i - c * G.nb;
+        og[(size_t)c * G.bins + G.bin0 + j] = from_f32<TOut>(G.slab[i]);
+      }
+    } else if (sizeof(TOut) == 4 && ((reinterpret_cast<uintptr_t>(og) & 15) == 0)) {
       const int n4 = n_out >> 2;
       for (int i = tid; i < n4; i += kRoiAlignThreads)
         reinterpret_cast<float4*>(og)[i] = reinterpret_cast<const float4*>(G.slab)[i];
@@ -399,6 +425,7 @@ __device__ __forceinline__ void run_passes(Stager& st, const LdsGeom& G, const T
     }
     __syncthreads();
   }
+ }
 }
 
 #ifndef DTC_RA_WAVES
@@ -464,12 +491,9 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   int x0 = xtab[0].lo;
   int ww = x1 - x0 + 1;
   const int wh = y1 - y0 + 1;
-  int npix = wh * ww;
-  // sub-tile width: largest CTs whose window (+1 dummy pixel) + output slab fit
   // the tables take what this RoI needs (28 entries for 7x7 bins x 2 samples), not the 4 KB worst case: ~3.5 KB more window
   const int tabf = ((ny + nx) * 4 + 15) & ~15;
   const int avail = lds_floats - tabf;
-  int cts = 0;
   // pixel-pair loads (StagerNCHW2) when rows start on even elements: dword pairs for fp16/bf16, dwordx2 pairs for fp32
   const bool pairs = p.pair_loads && (sizeof(TIn) == 2 || p.pair_loads > 1) && L.stride_c != 1 && L.stride_w == 1 &&
                      ((L.width | L.stride_h | L.stride_c | L.stride_n) & 1) == 0 &&
@@ -478,19 +502,37 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   if (pairs) {
     x0 = x0 & ~1;
     ww = ((x1 >> 1) - (x0 >> 1) + 1) * 2;
-    npix = wh * ww;
   }
-  // one dword per lane; the per-thread share of the window must fit the 32 prefetch registers (npix * cts <= 8192)
-  if (p.cts64 && pairs && cts == 0 && nc >= 64 && (npix / 2) * 64 <= pair_budget &&
-      (long long)(npix + 1) * (64 + kLdsPad) + 64LL * bins <= avail) cts = 64;
-  if (p.cts64 && !pairs && cts == 0 && L.stride_c != 1 && nc >= 64 && npix <= 128 &&
-      (long long)(npix + 1) * (64 + kLdsPad) + 64LL * bins <= avail) cts = 64;
-#pragma unroll
-  for (int c = 32; c >= 8; c >>= 1)
-    if (cts == 0 && npix <= kLdsMaxPix * (pairs ? 2 : 1) && (pairs ? (npix / 2) * c <= pair_budget : npix * c <= 8192) &&
-        (long long)(npix + 1) * (c + kLdsPad) + (long long)c * bins <= avail) cts = c;
+  // sub-tile width: largest CTs whose window of wh_ rows (+1 dummy pixel) + output slab fit; one dword per lane, the
+  // per-thread share of the window must fit the 32 prefetch registers (npix * cts <= 8192)
+  auto pick_cts = [&](int wh_) -> int {
+    const int np = wh_ * ww;
+    if (p.cts64 && pairs && nc >= 64 && (np / 2) * 64 <= pair_budget &&
+        (long long)(np + 1) * (64 + kLdsPad) + 64LL * bins <= avail) return 64;
+    if (p.cts64 && !pairs && L.stride_c != 1 && nc >= 64 && np <= 128 &&
+        (long long)(np + 1) * (64 + kLdsPad) + 64LL * bins <= avail) return 64;
+    for (int c = 32; c >= 8; c >>= 1)
+      if (np <= kLdsMaxPix * (pairs ? 2 : 1) && (pairs ? (np / 2) * c <= pair_budget : np * c <= 8192) &&
+          (long long)(np + 1) * (c + kLdsPad) + (long long)c * bins <= avail) return c;
+    return 0;
+  };
+  int cts = pick_cts(wh);
+  // A window that does not fit (adaptive sampling on a large RoI: the C4 configurations pool RoIs of up to 50 x 84 feature
+  // pixels) is pooled in GROUPS OF BIN ROWS: bin rows [ph0, ph1) only need the window rows their own samples touch, so the
+  // RoI is staged in 2..PH horizontal slices, each through the same LDS pipeline.  (Before: a per-output gather from global
+  // memory; 3.5 % of the C4 bench RoIs took 46 % of the launch.)
+  int rows = p.pooled_h, wh_max = wh;
+  for (int split = 2; split <= p.pooled_h && cts == 0; split++) {
+    rows = ceil_div(p.pooled_h, split);
+    wh_max = 0;
+    for (int ph0 = 0; ph0 < p.pooled_h; ph0 += rows) {
+      const int ph1 = min(p.pooled_h, ph0 + rows);
+      wh_max = max(wh_max, ytab[ph1 * gh - 1].hi - ytab[ph0 * gh].lo + 1);
+    }
+    cts = min(pick_cts(wh_max), 8);      // slices run through the largest register pipeline of the layout: 16 chunks x 8 channels
+  }
   if (cts == 0) {
-    // window too large for LDS: per-output gather straight from global (same arithmetic)
+    // not even one bin row fits: per-output gather straight from global (same arithmetic)
     for (int o = tid; o < nc * bins; o += kRoiAlignThreads) {
       const int c = o / bins, bin = o - c * bins;
       const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
@@ -511,22 +553,47 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
     }
     return;
   }
-  __syncthreads();
-  // rewrite the tables window-relative and premultiplied (in place: same entry size)
+  // rewrite the tables window-relative and premultiplied (in place: same entry size); a y entry is relative to the first
+  // window row of ITS bin-row group
   LdsAxis* yl = reinterpret_cast<LdsAxis*>(ytab);
   LdsAxis* xl = reinterpret_cast<LdsAxis*>(xtab);
-  if (tid < ny) { AxisEntry e = ytab[tid]; LdsAxis o; o.lo = (e.lo - y0) * ww * (cts + kLdsPad); o.hi = (e.hi - y0) * ww * (cts + kLdsPad); o.l = e.l; o.h = e.h; yl[tid] = o; }
-  else if (tid < ny + nx) { AxisEntry e = ytab[tid]; LdsAxis o; o.lo = (e.lo - x0) * (cts + kLdsPad); o.hi = (e.hi - x0) * (cts + kLdsPad); o.l = e.l; o.h = e.h; yl[tid] = o; }
+  const int ctp = cts + kLdsPad;
+  AxisEntry te; te.lo = te.hi = 0; te.l = te.h = 0.f;
+  int y0g = 0;
+  __syncthreads();                                   // every thread has read the absolute tables above
+  if (tid < ny + nx) {
+    te = ytab[tid];
+    if (tid < ny) y0g = ytab[((tid / gh) / rows) * rows * gh].lo;
+  }
+  __syncthreads();
+  if (tid < ny) { LdsAxis o; o.lo = (te.lo - y0g) * ww * ctp; o.hi = (te.hi - y0g) * ww * ctp; o.l = te.l; o.h = te.h; yl[tid] = o; }
+  else if (tid < ny + nx) { LdsAxis o; o.lo = (te.lo - x0) * ctp; o.hi = (te.hi - x0) * ctp; o.l = te.l; o.h = te.h; yl[tid] = o; }
   LdsGeom G;
   G.ytab = yl; G.xtab = xl;
-  G.slab = lds + tabf;                            // [cts][bins] output staging (16-float aligned)
+  G.slab = lds + tabf;                            // [cts][nb] output staging (16-float aligned)
   G.win = G.slab + cts * bins;                    // [npix + 1][cts + 4]  (cts*bins is a multiple of 4 -> 16 B aligned)
   G.cts = cts; G.bins = bins; G.gh = gh; G.gw = gw; G.pooled_w = p.pooled_w; G.nc = nc; G.count = count;
   G.inv_count = hd.inv_count;
   const TIn* cbase = fbase + (int64_t)c0 * L.stride_c;
+  const int npix_max = wh_max * ww;               // the register pipeline shape is chosen for the largest slice
+  G.rows = rows; G.pooled_h = p.pooled_h; G.x0 = x0; G.ww = ww; G.y0 = y0; G.wh = wh; G.height = L.height;
+  G.sh = sh; G.bin_h = bin_h; G.bin0 = 0; G.nb = bins;
+  if (rows != p.pooled_h) {        // sliced: the largest register pipeline of the layout, one instantiation
+    if (pairs) {
+      if constexpr (sizeof(TIn) == 2) { StagerNCHW2<TIn, 16, 2> st; run_passes<TIn, TOut, true>(st, G, L, cbase, L.stride_c, out); }
+      else { StagerNCHW2<TIn, 8, 2> st; run_passes<TIn, TOut, true>(st, G, L, cbase, L.stride_c, out); }
+    } else if (L.stride_c == 1) {
+      StagerNHWC<TIn> st;
+      run_passes<TIn, TOut, true>(st, G, L, cbase, L.stride_c, out);
+    } else {
+      StagerNCHW<TIn, 16, 2> st;
+      run_passes<TIn, TOut, true>(st, G, L, cbase, L.stride_c, out);
+    }
+    return;
+  }
   if (pairs) {
-    const int nkp = ceil_div(ceil_div(npix / 2, 16), kRoiAlignThreads / 64);
-#define DTC_RUN2(KK, GG) { StagerNCHW2<TIn, KK, GG> st; st.init(L, y0, x0, ww, wh, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
+    const int nkp = ceil_div(ceil_div(npix_max / 2, 16), kRoiAlignThreads / 64);
+#define DTC_RUN2(KK, GG) { StagerNCHW2<TIn, KK, GG> st; run_passes<TIn, TOut, false>(st, G, L, cbase, L.stride_c, out); }
     if constexpr (sizeof(TIn) == 2) {
       if (cts == 64) DTC_RUN2(2, 16)
       else if (nkp <= 4) DTC_RUN2(4, 8)
@@ -540,14 +607,14 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
     }
 #undef DTC_RUN2
   } else if (L.stride_c == 1) {
-    StagerNHWC<TIn> st; st.init(L, y0, x0, ww, wh, npix, cts);
-    run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out);
+    StagerNHWC<TIn> st;
+    run_passes<TIn, TOut, false>(st, G, L, cbase, L.stride_c, out);
   } else {
-    const int nk = ceil_div(ceil_div(npix, 16), kRoiAlignThreads / 64);
-    if (cts == 64) { StagerNCHW<TIn, 2, 16> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
-    else if (nk <= 4) { StagerNCHW<TIn, 4, 8> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
-    else if (nk <= 8) { StagerNCHW<TIn, 8, 4> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
-    else { StagerNCHW<TIn, 16, 2> st; st.init(L, y0, x0, ww, wh, npix, cts); run_passes<TIn, TOut>(st, G, cbase, L.stride_c, out); }
+    const int nk = ceil_div(ceil_div(npix_max, 16), kRoiAlignThreads / 64);
+    if (cts == 64) { StagerNCHW<TIn, 2, 16> st; run_passes<TIn, TOut, false>(st, G, L, cbase, L.stride_c, out); }
+    else if (nk <= 4) { StagerNCHW<TIn, 4, 8> st; run_passes<TIn, TOut, false>(st, G, L, cbase, L.stride_c, out); }
+    else if (nk <= 8) { StagerNCHW<TIn, 8, 4> st; run_passes<TIn, TOut, false>(st, G, L, cbase, L.stride_c, out); }
+    else { StagerNCHW<TIn, 16, 2> st; run_passes<TIn, TOut, false>(st, G, L, cbase, L.stride_c, out); }
   }
 }
 
