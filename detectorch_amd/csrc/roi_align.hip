@@ -382,23 +382,25 @@ __device__ __forceinline__ void run_passes(Stager& st, LdsGeom& G, const dtc_fea
     for (int lb = slot; lb < G.nb; lb += nslot) {
       const int bin = G.bin0 + lb;
       const int ph = bin / G.pooled_w, pw = bin - ph * G.pooled_w;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      // two channels per instruction (v_pk_mul_f32 / v_pk_add_f32: the IEEE results of the scalar forms at twice the rate)
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
       // reference order: for iy { for ix { acc += ... } }   (roi_align_cpu_loop.cpp:203-214)
       for (int iy = 0; iy < G.gh; iy++) {
         const LdsAxis y = G.ytab[ph * G.gh + iy];
         for (int ix = 0; ix < G.gw; ix++) {
           const LdsAxis x = G.xtab[pw * G.gw + ix];
           const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;       // roi_align_cpu_loop.cpp:95
-          const float4 v1 = *reinterpret_cast<const float4*>(wq + y.lo + x.lo);
-          const float4 v2 = *reinterpret_cast<const float4*>(wq + y.lo + x.hi);
-          const float4 v3 = *reinterpret_cast<const float4*>(wq + y.hi + x.lo);
-          const float4 v4 = *reinterpret_cast<const float4*>(wq + y.hi + x.hi);
-          a0 += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;                               // :208-211
-          a1 += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
-          a2 += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
-          a3 += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(wq + y.lo + x.lo);
+          const f32x4 v2 = *reinterpret_cast<const f32x4*>(wq + y.lo + x.hi);
+          const f32x4 v3 = *reinterpret_cast<const f32x4*>(wq + y.hi + x.lo);
+          const f32x4 v4 = *reinterpret_cast<const f32x4*>(wq + y.hi + x.hi);
+          a01 += w1 * v1.lo + w2 * v2.lo + w3 * v3.lo + w4 * v4.lo;                           // :208-211
+          a23 += w1 * v1.hi + w2 * v2.hi + w3 * v3.hi + w4 * v4.hi;
         }
       }
+      const float a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
       float* so = G.slab + (cq * 4) * G.nb + lb;
       if (G.inv_count != 0.f) {                                                               // :216
         so[0] = a0 * G.inv_count; so[G.nb] = a1 * G.inv_count; so[2 * G.nb] = a2 * G.inv_count; so[3 * G.nb] = a3 * G.inv_count;
@@ -759,17 +761,19 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
 // ---- host side ------------------------------------------------------------------------------------------------------------
 // Development / A-B knobs, resolved ONCE per process (thread-safe static initialisation) -- not per dispatch:
 //   DTC_ROIALIGN_TILE=0          use the RoI-stationary kernel of this file instead of the cluster-stationary one (roi_align_tile.hip)
+//   DTC_ROIALIGN_MAP=0           single-level inputs (C4) through the RoI-stationary kernel instead of the map-stationary one (roi_align_map.hip)
 //   DTC_ROIALIGN_GENERAL=1       force the per-output gather kernel (the plain statement of the arithmetic)
 //   DTC_ROIALIGN_NO_NHWC_DIRECT  channels_last features through the LDS-staged kernel
 //   DTC_ROIALIGN_LDS_KB (52)  DTC_RA_CHBLOCK (128 / 64)  DTC_RA_NO_XCD  DTC_RA_NO_CTS64  DTC_RA_NO_PAIRS  DTC_RA_PAIRS32
 struct RoiAlignConfig {
-  bool tile = true, general = false, nhwc_direct = true, xcd = true, cts64 = true;
+  bool tile = true, map = true, general = false, nhwc_direct = true, xcd = true, cts64 = true;
   int pair_loads = 1, ch_block = 0, lds_bytes = 52 * 1024;
 };
 static const RoiAlignConfig& roi_align_config() {
   static const RoiAlignConfig cfg = [] {
     RoiAlignConfig c;
     if (const char* e = getenv("DTC_ROIALIGN_TILE")) c.tile = e[0] != '0';
+    if (const char* e = getenv("DTC_ROIALIGN_MAP")) c.map = e[0] != '0';
     c.general = getenv("DTC_ROIALIGN_GENERAL") != nullptr;
     c.nhwc_direct = getenv("DTC_ROIALIGN_NO_NHWC_DIRECT") == nullptr;
     c.xcd = getenv("DTC_RA_NO_XCD") == nullptr;
@@ -882,6 +886,9 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   // in LDS wins (0.21 vs 0.37 ms), and the LDS kernel stages channels_last windows with 16-byte loads too.
   const bool few_taps = sampling_ratio > 0 && (long long)pooled_h * pooled_w * sampling_ratio * sampling_ratio <= 256;
   if (lds_ok && all_nhwc && few_taps && cfg.nhwc_direct) return dtc::launch_typed(dtc::kKernNhwc, p, in_dtype, out_dtype, s);
+  // one level whose whole map fits LDS (the C4 heads), adaptive sampling: the map-stationary kernel (roi_align_map.hip)
+  if (cfg.map && !cfg.general && sampling_ratio != 2 && dtc::roi_align_map_supported(p, in_dtype, out_dtype))
+    return dtc::launch_roi_align_map(p, in_dtype, out_dtype, s);
   // NCHW (the reference's layout), sampling_ratio 2: the cluster-stationary kernel (roi_align_tile.hip)
   if (cfg.tile && !all_nhwc && !cfg.general && dtc::roi_align_tile_supported(p, in_dtype, out_dtype))
     return dtc::launch_roi_align_tile(p, in_dtype, out_dtype, s);

@@ -1,0 +1,280 @@
+// A1  RoIAlign forward, MAP-stationary kernel: the single-level (C4) configurations with adaptive sampling.
+//
+// Replaces roi_align_forward_kernel (lib/cppcuda_cffi/src/cuda/roi_align_forward_cuda.cu:82-159) for the R-50-C4 heads
+// (detector.py:240-248: RoIAlign on res4, [B,1024,50,84], sampling_ratio 0 -> ceil(roi / pooled) samples per bin and axis).
+//
+// Why a third formulation: on one stride-16 map every RoI is large relative to the map (a 512-pixel proposal covers a quarter
+// of it), RoIs overlap many-fold and the adaptive grid makes 4..400 taps per bin.  A RoI-stationary workgroup stages its window
+// once per 128 channels: 8000 RoIs x 1024 channels re-read 6.4 GB of features that hold 0.14 GB (measured: the same launch is
+// 3.5 x slower when the RoI order destroys L2 locality), and a large window leaves room for only 8 channels per pass.  But the
+// whole map of a channel quad is 50 x 84 x 16 B = 67 KB: it FITS the 160 KB LDS of a CU.  So here a workgroup owns
+// (a run of RoIs, 8 channels), stages the ENTIRE map of those channels once (every feature byte is read once per run), and its
+// 16 wavefronts pool one RoI each, lane <-> bin, straight from LDS:
+//   * no window, no axis tables, no per-RoI barriers: a wave needs a workgroup barrier only when the image changes;
+//   * sampling positions and weights (make_axis: the reference's own operations, roi_align_cpu_loop.cpp:36-95) are formed once per
+//     RoI, one axis entry per lane, and fetched in the sample loops with wave shuffles; waves take RoIs from a shared counter
+//     (the cost of a RoI varies 1 : 100 with the adaptive grid);
+//   * a tap is one ds_read_b128 per channel quad, accumulated with packed fp32 multiplies / adds in the reference's order
+//     (for iy, for ix: acc += w1*v1 + w2*v2 + w3*v3 + w4*v4 ; /= count) -> bit-identical to the CPU reference;
+//   * the [8 channels][bins] results of a RoI are contiguous in the [R,C,PH,PW] output: they go through a per-wave LDS slab
+//     and leave as 16-byte stores.
+// RoIs must arrive image-major (the packed descriptors of dtc_fpn_collect_distribute are); any order is CORRECT, but every
+// change of image re-stages the map.
+#include <mutex>
+
+#include "roi_align_common.h"
+
+namespace dtc {
+
+constexpr int kMapThreads = 1024;
+constexpr int kMapWaves = kMapThreads / 64;
+constexpr int kMapLdsBytes = 160 * 1024 - 512;      // dynamic LDS budget (static: the rendezvous arrays)
+
+typedef float mf32x2 __attribute__((ext_vector_type(2)));
+typedef float mf32x4 __attribute__((ext_vector_type(4)));
+
+template <typename TOut> __device__ __forceinline__ void map_store4(TOut* d, float4 v);
+template <> __device__ __forceinline__ void map_store4<float>(float* d, float4 v) { *reinterpret_cast<float4*>(d) = v; }
+template <> __device__ __forceinline__ void map_store4<__half>(__half* d, float4 v) {
+  const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+  uint2 r; r.x = *reinterpret_cast<const uint32_t*>(&a); r.y = *reinterpret_cast<const uint32_t*>(&b);
+  *reinterpret_cast<uint2*>(d) = r;
+}
+template <> __device__ __forceinline__ void map_store4<bf16_t>(bf16_t* d, float4 v) {
+  uint2 r;
+  r.x = (uint32_t)from_f32<bf16_t>(v.x).bits | ((uint32_t)from_f32<bf16_t>(v.y).bits << 16);
+  r.y = (uint32_t)from_f32<bf16_t>(v.z).bits | ((uint32_t)from_f32<bf16_t>(v.w).bits << 16);
+  *reinterpret_cast<uint2*>(d) = r;
+}
+
+// One sample of one bin: 4 taps x NQ channel quads.  ylo / yhi: byte offsets of the two rows, xlo / xhi of the two columns.
+template <int NQ>
+__device__ __forceinline__ void map_sample(const char* map, int plane_bytes, int ylo, int yhi, int xlo, int xhi, float yl,
+                                           float yh, float xl, float xh, mf32x2 (&acc)[NQ][2]) {
+  const float w1 = yh * xh, w2 = yh * xl, w3 = yl * xh, w4 = yl * xl;                          // roi_align_cpu_loop.cpp:95
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const char* m = map + q * plane_bytes;
+    const mf32x4 v1 = *reinterpret_cast<const mf32x4*>(__builtin_assume_aligned(m + ylo + xlo, 16));
+    const mf32x4 v2 = *reinterpret_cast<const mf32x4*>(__builtin_assume_aligned(m + ylo + xhi, 16));
+    const mf32x4 v3 = *reinterpret_cast<const mf32x4*>(__builtin_assume_aligned(m + yhi + xlo, 16));
+    const mf32x4 v4 = *reinterpret_cast<const mf32x4*>(__builtin_assume_aligned(m + yhi + xhi, 16));
+    acc[q][0] += w1 * v1.lo + w2 * v2.lo + w3 * v3.lo + w4 * v4.lo;                               // :208-211
+    acc[q][1] += w1 * v1.hi + w2 * v2.hi + w3 * v3.hi + w4 * v4.hi;
+  }
+}
+
+__device__ __forceinline__ int map_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <typename TIn, typename TOut, int NQ>
+__global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams p, int seg_len, int use_slab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int pend_idx[kMapWaves];
+  __shared__ int pend_img[kMapWaves];
+  __shared__ int s_next;                                          // next RoI of the run nobody has taken yet
+  const dtc_feat_level L = p.lv[0];
+  const int H = L.height, W = L.width, HW = H * W;
+  const int plane_bytes = HW * 16;
+  const char* map = reinterpret_cast<const char*>(smem);          // [NQ][H*W][4 channels] float32
+  float* mapw = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int bins = p.pooled_h * p.pooled_w;
+  float* slab = reinterpret_cast<float*>(smem + NQ * plane_bytes) + (size_t)wv * (4 * NQ) * bins;   // [4 NQ][bins], use_slab only
+  constexpr int CG = 4 * NQ;
+  const int ncg = ceil_div(p.channels, CG);
+  const int cg = blockIdx.x % ncg, seg = blockIdx.x / ncg;
+  const int c0 = cg * CG, nc = min(CG, p.channels - c0);
+  const int r_end = min(p.n_rois, (seg + 1) * seg_len);
+  TOut* out = reinterpret_cast<TOut*>(p.out);
+  if (tid == 0) s_next = seg * seg_len;
+  __syncthreads();
+  int cur = -1;                               // image whose map is staged (uniform)
+  int ri = -1;                                // the RoI this wave holds (taken from s_next; kept across a change of image)
+  for (;;) {
+    int want = -1;
+    // ---- pool RoIs of the staged image; waves take them one by one (their cost varies 1 : 100 with the adaptive grid) -----
+    for (;;) {
+      if (ri < 0) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(&s_next, 1);
+        ri = map_uni(t);
+      }
+      if (ri >= r_end) break;
+      const RoiHead hd = load_roi_head(p, ri);
+      const bool padrow = hd.lvl < 0 || hd.lvl >= p.n_levels;
+      if (!padrow && hd.b != cur) { want = hd.b; break; }           // needs another image: keep the RoI, go to the rendezvous
+      TOut* orow = out + ((size_t)hd.r * p.channels + c0) * bins;
+      if (padrow) {                            // padding row of a fixed-shape batch: defined output
+        for (int o = lane; o < nc * bins; o += 64) orow[o] = from_f32<TOut>(0.f);
+        ri = -1;
+        continue;
+      }
+      // everything about the RoI is uniform across the wave: scalar registers, scalar loops
+      const int gh = map_uni(hd.gh), gw = map_uni(hd.gw);
+      const float sh = __uint_as_float(map_uni(__float_as_uint(hd.sh))), sw = __uint_as_float(map_uni(__float_as_uint(hd.sw)));
+      const float bin_h = __uint_as_float(map_uni(__float_as_uint(hd.bin_h))), bin_w = __uint_as_float(map_uni(__float_as_uint(hd.bin_w)));
+      // Axis entries (roi_align_cpu_loop.cpp:36-95) are formed ONCE per RoI, entry e = (bin row e / gh, sample e % gh) by lane e,
+      // and fetched inside the sample loops with wave shuffles (ds_bpermute): no divisions, no float -> int in the loops.  More
+      // than 64 entries per axis (a RoI of >= 10 x the pooled size): formed on the fly instead.
+      const bool ytab = p.pooled_h * gh <= 64, xtab = p.pooled_w * gw <= 64;
+      const AxisEntry ey = make_axis(sh, bin_h, min(lane / gh, p.pooled_h - 1), lane % gh, gh, H);
+      const AxisEntry ex = make_axis(sw, bin_w, min(lane / gw, p.pooled_w - 1), lane % gw, gw, W);
+      const int ey_lo = ey.lo * W * 16, ey_hi = ey.hi * W * 16, ex_lo = ex.lo << 4, ex_hi = ex.hi << 4;
+#pragma unroll 1
+      for (int b0 = 0; b0 < bins; b0 += 64) {
+        const int bin = min(b0 + lane, bins - 1);        // lanes past the last bin repeat it (uniform control flow), never stored
+        const bool on = b0 + lane < bins;
+        const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
+        mf32x2 acc[NQ][2];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { acc[q][0] = mf32x2{0.f, 0.f}; acc[q][1] = mf32x2{0.f, 0.f}; }
+        // reference order: for iy { for ix { acc += ... } }   (roi_align_cpu_loop.cpp:203-214)
+#pragma unroll 1
+        for (int iy = 0; iy < gh; iy++) {
+          int ylo, yhi; float yl, yh;
+          if (ytab) {
+            const int src = ph * gh + iy;
+            ylo = __shfl(ey_lo, src, 64); yhi = __shfl(ey_hi, src, 64); yl = __shfl(ey.l, src, 64); yh = __shfl(ey.h, src, 64);
+          } else {
+            const AxisEntry y = make_axis(sh, bin_h, ph, iy, gh, H);
+            ylo = y.lo * W * 16; yhi = y.hi * W * 16; yl = y.l; yh = y.h;
+          }
+#pragma unroll 1
+          for (int ix = 0; ix < gw; ix++) {
+            int xlo, xhi; float xl, xh;
+            if (xtab) {
+              const int src = pw * gw + ix;
+              xlo = __shfl(ex_lo, src, 64); xhi = __shfl(ex_hi, src, 64); xl = __shfl(ex.l, src, 64); xh = __shfl(ex.h, src, 64);
+            } else {
+              const AxisEntry x = make_axis(sw, bin_w, pw, ix, gw, W);
+              xlo = x.lo << 4; xhi = x.hi << 4; xl = x.l; xh = x.h;
+            }
+            map_sample<NQ>(map, plane_bytes, ylo, yhi, xlo, xhi, yl, yh, xl, xh, acc);
+          }
+        }
+        float res[CG];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          res[4 * q + 0] = acc[q][0].x; res[4 * q + 1] = acc[q][0].y; res[4 * q + 2] = acc[q][1].x; res[4 * q + 3] = acc[q][1].y;
+        }
+#pragma unroll
+        for (int c = 0; c < CG; c++)             // :216  output_val /= count
+          res[c] = hd.inv_count != 0.f ? res[c] * hd.inv_count : fdiv(res[c], hd.count);
+        if (use_slab) {
+          // bins <= 64, whole channel quads: [CG][bins] is ONE contiguous run of the output -> wave-private slab, 16-byte stores
+          if (on) {
+#pragma unroll
+            for (int c = 0; c < CG; c++) slab[c * bins + bin] = res[c];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const int n4 = (CG * bins) >> 2;
+          for (int i = lane; i < n4; i += 64) map_store4<TOut>(orow + 4 * i, reinterpret_cast<const float4*>(slab)[i]);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        } else if (on) {
+#pragma unroll
+          for (int c = 0; c < CG; c++)
+            if (c < nc) orow[(size_t)c * bins + bin] = from_f32<TOut>(res[c]);
+        }
+      }
+      ri = -1;
+    }
+    // ---- rendezvous: every wave has finished the staged image (or the run); the lowest waiting RoI names the next image ----
+    if (lane == 0) { pend_idx[wv] = want >= 0 ? ri : 0x7fffffff; pend_img[wv] = want; }
+    __syncthreads();
+    int best = 0x7fffffff, img = -1;
+#pragma unroll
+    for (int w = 0; w < kMapWaves; w++) {
+      const int pi = pend_idx[w];
+      if (pi < best) { best = pi; img = pend_img[w]; }
+    }
+    if (best == 0x7fffffff) break;            // uniform: nothing left
+    // ---- stage the whole map of image `img`, channels [c0, c0 + nc): [quad][pixel][4 channels] float32 ------------------
+    const TIn* src = reinterpret_cast<const TIn*>(L.data) + (int64_t)img * L.stride_n + (int64_t)c0 * L.stride_c;
+    const bool rows_contig = L.stride_w == 1 && L.stride_h == W;
+    for (int e = tid; e < CG * HW; e += kMapThreads) {
+      const int c = e / HW, px = e - c * HW;
+      const int cc = min(c, nc - 1);                                  // channel tail: duplicate the last plane, never stored
+      int64_t off = (int64_t)cc * L.stride_c;
+      if (rows_contig) off += px;
+      else { const int row = px / W, col = px - row * W; off += (int64_t)row * L.stride_h + (int64_t)col * L.stride_w; }
+      mapw[((size_t)(c >> 2) * HW + px) * 4 + (c & 3)] = to_f32<TIn>(src[off]);
+    }
+    __syncthreads();
+    cur = img;
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+static int map_nq(const RoiAlignParams& p, int* use_slab) {
+  const long long HW = (long long)p.lv[0].height * p.lv[0].width;
+  const int bins = p.pooled_h * p.pooled_w;
+  const bool slab_ok = bins <= 64 && (p.channels & 3) == 0;
+  for (int nq = 2; nq >= 1; nq--) {
+    if ((p.channels % (4 * nq)) != 0 && nq > 1) continue;            // whole channel groups (a tail only with single quads)
+    const long long slab = slab_ok ? (long long)kMapWaves * 4 * nq * bins * 4 : 0;
+    if (HW * 16 * nq + slab <= kMapLdsBytes) { *use_slab = slab_ok ? 1 : 0; return nq; }
+    if (HW * 16 * nq <= kMapLdsBytes) { *use_slab = 0; return nq; }
+  }
+  return 0;
+}
+
+bool roi_align_map_supported(const RoiAlignParams& p, int in_dtype, int out_dtype) {
+  if (p.n_levels != 1) return false;
+  if (!(p.roi_desc || p.roi_cols == 4)) return false;                // image-major order is known only for these callers
+  if (p.lv[0].stride_c == 1 && p.channels > 1) return false;         // channels_last: the NHWC / LDS kernels
+  if ((long long)p.n_rois * p.channels < 64 * 1024) return false;    // too little work to pay for staging whole maps
+  int slab;
+  if (map_nq(p, &slab) == 0) return false;
+  const bool f = in_dtype == DTC_F32, h = in_dtype == DTC_F16, b = in_dtype == DTC_BF16;
+  return (f && (out_dtype == DTC_F32 || out_dtype == DTC_F16 || out_dtype == DTC_BF16)) ||
+         (h && (out_dtype == DTC_F32 || out_dtype == DTC_F16)) || (b && (out_dtype == DTC_F32 || out_dtype == DTC_BF16));
+}
+
+template <typename TIn, typename TOut, int NQ>
+static int launch_map_nq(const RoiAlignParams& p, int use_slab, hipStream_t stream) {
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_map<TIn, TOut, NQ>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kMapLdsBytes);
+  });
+  if (attr_rc != hipSuccess) return DTC_ELAUNCH;
+  const int bins = p.pooled_h * p.pooled_w;
+  const int ncg = ceil_div(p.channels, 4 * NQ);
+  // runs of RoIs per workgroup: ~8 workgroups per CU over the launch (one is resident per CU), at least 8 RoIs per wave
+  int n_seg = (8 * 256 + ncg - 1) / ncg;
+  int seg_len = ceil_div(p.n_rois, n_seg < 1 ? 1 : n_seg);
+  if (seg_len < 8 * kMapWaves) seg_len = 8 * kMapWaves;
+  seg_len = ceil_div(seg_len, kMapWaves) * kMapWaves;
+  n_seg = ceil_div(p.n_rois, seg_len);
+  const size_t lds = (size_t)p.lv[0].height * p.lv[0].width * 16 * NQ + (use_slab ? (size_t)kMapWaves * 4 * NQ * bins * 4 : 0);
+  hipLaunchKernelGGL((roi_align_fwd_map<TIn, TOut, NQ>), dim3((unsigned)(ncg * n_seg)), dim3(kMapThreads), lds, stream, p,
+                     seg_len, use_slab);
+  DTC_CHECK_LAUNCH();
+  return DTC_OK;
+}
+
+template <typename TIn, typename TOut>
+static int launch_map_t(const RoiAlignParams& p, hipStream_t stream) {
+  int use_slab = 0;
+  const int nq = map_nq(p, &use_slab);
+  if (nq == 2) return launch_map_nq<TIn, TOut, 2>(p, use_slab, stream);
+  if (nq == 1) return launch_map_nq<TIn, TOut, 1>(p, use_slab, stream);
+  return DTC_EUNSUPPORTED;
+}
+
+int launch_roi_align_map(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream) {
+  if (p.n_rois == 0) return DTC_OK;
+  if (in_dtype == DTC_F32 && out_dtype == DTC_F32) return launch_map_t<float, float>(p, stream);
+  if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return launch_map_t<__half, float>(p, stream);
+  if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return launch_map_t<__half, __half>(p, stream);
+  if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return launch_map_t<float, __half>(p, stream);
+  if (in_dtype == DTC_BF16 && out_dtype == DTC_F32) return launch_map_t<bf16_t, float>(p, stream);
+  if (in_dtype == DTC_BF16 && out_dtype == DTC_BF16) return launch_map_t<bf16_t, bf16_t>(p, stream);
+  if (in_dtype == DTC_F32 && out_dtype == DTC_BF16) return launch_map_t<float, bf16_t>(p, stream);
+  return DTC_EUNSUPPORTED;
+}
+
+}  // namespace dtc

@@ -179,6 +179,65 @@ def test_ordered_and_packed_entry_points(hip, oracle):
     assert np.array_equal(res[:200], ref) and not res[200].any()
 
 
+def _c4_rois(rs, n, im_h=800, im_w=1333):
+    """proposals of all sizes on a stride-16 map: from 2 x 2 feature pixels to most of the image (adaptive grids 1 .. 12)"""
+    side = np.exp(rs.uniform(np.log(24), np.log(1100), (n, 2)))
+    cx, cy = rs.uniform(0, im_w, n), rs.uniform(0, im_h, n)
+    x1, y1 = np.clip(cx - side[:, 0] / 2, 0, im_w - 1), np.clip(cy - side[:, 1] / 2, 0, im_h - 1)
+    x2, y2 = np.clip(cx + side[:, 0] / 2, 0, im_w - 1), np.clip(cy + side[:, 1] / 2, 0, im_h - 1)
+    return np.stack([x1, y1, x2, y2], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["p7_slab", "p14_direct", "tail_c50", "fp16", "shuffled", "sr3", "col4"])
+def test_map_stationary_kernel_vs_oracle(hip, oracle, case):
+    """The single-level (C4) kernel roi_align_fwd_map: whole map of 8 channels in LDS, one RoI per wavefront.  Packed
+    descriptors as dtc_fpn_collect_distribute emits them (image-major, with padding rows), adaptive sampling; 7x7 bins (LDS
+    slab + 16-byte stores), 14x14 bins (direct stores, 4 bin chunks per RoI), a channel count that is not a multiple of 4
+    (single quads, clamped tail), fp16 features, a NOT image-major order (every change of image re-stages the map: slow,
+    still exact), a fixed non-2 sampling ratio, and the 4-column (single image) plain entry."""
+    rs = synth.rng(8, 77)
+    B, H, W = 3, 50, 84
+    C = 50 if case == "tail_c50" else 128
+    ph = pw = 14 if case == "p14_direct" else 7
+    sr = 3 if case == "sr3" else 0
+    n = 700 if C == 128 else 1500           # R * C >= 64 K: below that the dispatcher keeps the RoI-stationary kernel
+    feat = synth.make_features(rs, (B, C, H, W))
+    if case == "fp16":
+        feat = feat.astype(np.float16).astype(np.float32)
+    rois = _c4_rois(rs, n)
+    img = np.sort(rs.randint(0, B, n)).astype(np.float32)
+    if case == "col4":
+        img[:] = 0
+    rois5 = np.hstack([img[:, None], rois]).astype(np.float32)
+    ref = oracle.roi_align_forward(feat, rois5, ph, pw, 1 / 16., sr)
+    tf = cu(feat).half() if case == "fp16" else cu(feat)
+    if case == "col4":
+        out = hip.roi_align_forward(tf[:1].contiguous(), 1 / 16., cu(rois), ph, pw, sr).cpu().numpy()
+        assert np.array_equal(out, ref)
+        return
+    order = np.arange(n)
+    if case == "shuffled":
+        order = rs.permutation(n)
+    desc = np.zeros((n + 5, 8), np.float32)
+    desc[:n, :5] = rois5[order]
+    desc[:n, 6] = order
+    pad_rows = np.arange(n, n + 5)
+    desc[n:, 5] = -1
+    desc[n:, 6] = pad_rows
+    # padding rows interleaved at the image boundaries, like the fixed-shape batches of the fused path
+    perm = np.argsort(np.concatenate([np.arange(n), np.linspace(0, n - 1, 5)]), kind="stable")
+    desc = desc[perm]
+    out = torch.full((n + 5, C, ph, pw), 3.0, device="cuda")
+    lvs, ch, dt = hip.make_levels([tf], [1 / 16.])
+    rc = hip.lib().dtc_roi_align_forward_packed(lvs, 1, ch, hip._dtype_code(dt), cu(desc).data_ptr(), n + 5, ph, pw, sr,
+                                                out.data_ptr(), 0, hip.stream_ptr())
+    assert rc == 0
+    res = out.cpu().numpy()
+    assert not res[n:].any()
+    assert np.abs(res[:n] - ref).max() <= TOL
+    assert np.array_equal(res[:n], ref)
+
+
 _VARIANT_CHILD = r"""
 import sys, os, numpy as np, torch
 root = %r

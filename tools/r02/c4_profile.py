@@ -31,8 +31,11 @@ for lo, hi in [(0, 64), (64, 256), (256, 512), (512, 1024), (1024, 2048), (2048,
     print("  window [%5.0f, %5.0f): %5d rois (%.1f %%)  mean samples/bin %.1f" % (lo, hi, m.sum(), 100 * m.mean(), (gw * gh)[m].mean() if m.any() else 0))
 
 
-def time_subset(mask, tag):
-    idx = valid[torch.from_numpy(np.nonzero(mask)[0]).to(dev)]
+def time_subset(mask, tag, order=None):
+    sel = np.nonzero(mask)[0]
+    if order is not None:
+        sel = sel[order]
+    idx = valid[torch.from_numpy(sel).to(dev)]
     rr = rois5[idx].contiguous()
     if len(rr) == 0:
         return
@@ -52,3 +55,5 @@ print("time by class (unsorted order within a class):")
 for lo, hi in [(0, 64), (64, 256), (256, 512), (512, 1024), (1024, 2048), (2048, 1e9)]:
     time_subset((win >= lo) & (win < hi), "window [%d, %d)" % (lo, hi))
 time_subset(np.ones(len(win), bool), "all")
+time_subset(np.ones(len(win), bool), "all, largest first", order=np.argsort(-win, kind="stable"))
+time_subset(np.ones(len(win), bool), "all, smallest first", order=np.argsort(win, kind="stable"))
