@@ -67,21 +67,31 @@ struct RoiHead {
   float count, inv_count;     // :173 ; inv_count != 0 when count is a power of two (x * inv_count == x / count exactly)
 };
 
-__device__ __forceinline__ RoiHead load_roi_head(const RoiAlignParams& p, int ri) {
-  RoiHead h;
-  float x1, y1, x2, y2;
-  h.b = 0;
+// The raw record of RoI ri in processing order -- (batch, x1, y1, x2) (y2, level, output row, 0) -- split from the geometry
+// so that a kernel can issue the loads of its NEXT RoI before it pools the current one.
+struct RoiRaw { float4 d0, d1; };
+
+__device__ __forceinline__ RoiRaw load_roi_raw(const RoiAlignParams& p, int ri) {
+  RoiRaw w;
   if (p.roi_desc) {   // one packed 32-byte descriptor in visiting order
-    const float4 d0 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2];
-    const float4 d1 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2 + 1];
-    h.b = (int)d0.x; x1 = d0.y; y1 = d0.z; x2 = d0.w; y2 = d1.x; h.lvl = (int)d1.y; h.r = (int)d1.z;
+    w.d0 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2];
+    w.d1 = reinterpret_cast<const float4*>(p.roi_desc)[(size_t)ri * 2 + 1];
   } else {
-    h.r = p.roi_order ? p.roi_order[ri] : ri;
-    h.lvl = p.roi_levels ? p.roi_levels[h.r] : 0;
-    const float* roi = p.rois + (size_t)h.r * p.roi_cols;
-    if (p.roi_cols == 5) { h.b = (int)roi[0]; roi++; }          // :143-147
-    x1 = roi[0]; y1 = roi[1]; x2 = roi[2]; y2 = roi[3];
+    const int r = p.roi_order ? p.roi_order[ri] : ri;
+    const int lvl = p.roi_levels ? p.roi_levels[r] : 0;
+    const float* roi = p.rois + (size_t)r * p.roi_cols;
+    float b = 0.f;
+    if (p.roi_cols == 5) { b = roi[0]; roi++; }                 // :143-147
+    w.d0 = make_float4(b, roi[0], roi[1], roi[2]);
+    w.d1 = make_float4(roi[3], (float)lvl, (float)r, 0.f);
   }
+  return w;
+}
+
+__device__ __forceinline__ RoiHead roi_head_from_raw(const RoiAlignParams& p, const RoiRaw& w) {
+  RoiHead h;
+  h.b = (int)w.d0.x; h.lvl = (int)w.d1.y; h.r = (int)w.d1.z;
+  const float x1 = w.d0.y, y1 = w.d0.z, x2 = w.d0.w, y2 = w.d1.x;
   h.sw = h.sh = 0.f; h.rw = h.rh = 1.f; h.bin_h = h.bin_w = 1.f; h.gh = h.gw = 1; h.count = 1.f; h.inv_count = 1.f;
   if (h.lvl < 0 || h.lvl >= p.n_levels) return h;
   const float s = p.lv[h.lvl].spatial_scale;
@@ -95,6 +105,10 @@ __device__ __forceinline__ RoiHead load_roi_head(const RoiAlignParams& p, int ri
   h.count = (float)gg;
   h.inv_count = ((gg & (gg - 1)) == 0) ? fdiv(1.f, h.count) : 0.f;
   return h;
+}
+
+__device__ __forceinline__ RoiHead load_roi_head(const RoiAlignParams& p, int ri) {
+  return roi_head_from_raw(p, load_roi_raw(p, ri));
 }
 
 // launchers of the cluster-stationary kernel (roi_align_tile.hip); in_dtype / out_dtype are DTC_* codes

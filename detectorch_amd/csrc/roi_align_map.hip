@@ -47,6 +47,19 @@ template <> __device__ __forceinline__ void map_store4<bf16_t>(bf16_t* d, float4
   *reinterpret_cast<uint2*>(d) = r;
 }
 
+template <typename TIn> struct MapLoad4;
+template <> struct MapLoad4<float> { static __device__ __forceinline__ float4 ld(const float* p) { return *reinterpret_cast<const float4*>(p); } };
+template <> struct MapLoad4<__half> {
+  static __device__ __forceinline__ float4 ld(const __half* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    const __half2 a = *reinterpret_cast<const __half2*>(&r.x), b = *reinterpret_cast<const __half2*>(&r.y);
+    return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
+  }
+};
+template <> struct MapLoad4<bf16_t> {
+  static __device__ __forceinline__ float4 ld(const bf16_t* p) { return bf16x4_to_f32(*reinterpret_cast<const uint2*>(p)); }
+};
+
 // One sample of one bin: 4 taps x NQ channel quads.  ylo / yhi: byte offsets of the two rows, xlo / xhi of the two columns.
 template <int NQ>
 __device__ __forceinline__ void map_sample(const char* map, int plane_bytes, int ylo, int yhi, int xlo, int xhi, float yl,
@@ -86,27 +99,36 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
   const int c0 = cg * CG, nc = min(CG, p.channels - c0);
   const int r_end = min(p.n_rois, (seg + 1) * seg_len);
   TOut* out = reinterpret_cast<TOut*>(p.out);
+  const float rpw = __frcp_rn((float)p.pooled_w);
   if (tid == 0) s_next = seg * seg_len;
   __syncthreads();
   int cur = -1;                               // image whose map is staged (uniform)
   int ri = -1;                                // the RoI this wave holds (taken from s_next; kept across a change of image)
+  RoiRaw raw;                                 // ... and its record
+  raw.d0 = raw.d1 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (;;) {
     int want = -1;
     // ---- pool RoIs of the staged image; waves take them one by one (their cost varies 1 : 100 with the adaptive grid) -----
     for (;;) {
-      if (ri < 0) {
+      if (ri < 0) {                            // nothing held: take a RoI and fetch its record
         int t = 0;
         if (lane == 0) t = atomicAdd(&s_next, 1);
         ri = map_uni(t);
+        if (ri < r_end) raw = load_roi_raw(p, ri);
       }
       if (ri >= r_end) break;
-      const RoiHead hd = load_roi_head(p, ri);
+      const RoiHead hd = roi_head_from_raw(p, raw);
       const bool padrow = hd.lvl < 0 || hd.lvl >= p.n_levels;
       if (!padrow && hd.b != cur) { want = hd.b; break; }           // needs another image: keep the RoI, go to the rendezvous
+      // take the NEXT RoI now: its record is in flight while this one is pooled
+      int rn;
+      { int t = 0; if (lane == 0) t = atomicAdd(&s_next, 1); rn = map_uni(t); }
+      RoiRaw rawn = raw;
+      if (rn < r_end) rawn = load_roi_raw(p, rn);
       TOut* orow = out + ((size_t)hd.r * p.channels + c0) * bins;
       if (padrow) {                            // padding row of a fixed-shape batch: defined output
         for (int o = lane; o < nc * bins; o += 64) orow[o] = from_f32<TOut>(0.f);
-        ri = -1;
+        ri = rn; raw = rawn;
         continue;
       }
       // everything about the RoI is uniform across the wave: scalar registers, scalar loops
@@ -117,14 +139,16 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
       // and fetched inside the sample loops with wave shuffles (ds_bpermute): no divisions, no float -> int in the loops.  More
       // than 64 entries per axis (a RoI of >= 10 x the pooled size): formed on the fly instead.
       const bool ytab = p.pooled_h * gh <= 64, xtab = p.pooled_w * gw <= 64;
-      const AxisEntry ey = make_axis(sh, bin_h, min(lane / gh, p.pooled_h - 1), lane % gh, gh, H);
-      const AxisEntry ex = make_axis(sw, bin_w, min(lane / gw, p.pooled_w - 1), lane % gw, gw, W);
+      // lane / g for the uniform small g: (lane + .5) * (1 / g) truncated is exact (the product is >= .5 / g away from an integer)
+      const int qy = (int)(((float)lane + 0.5f) * __frcp_rn((float)gh)), qx = (int)(((float)lane + 0.5f) * __frcp_rn((float)gw));
+      const AxisEntry ey = make_axis(sh, bin_h, min(qy, p.pooled_h - 1), lane - qy * gh, gh, H);
+      const AxisEntry ex = make_axis(sw, bin_w, min(qx, p.pooled_w - 1), lane - qx * gw, gw, W);
       const int ey_lo = ey.lo * W * 16, ey_hi = ey.hi * W * 16, ex_lo = ex.lo << 4, ex_hi = ex.hi << 4;
 #pragma unroll 1
       for (int b0 = 0; b0 < bins; b0 += 64) {
         const int bin = min(b0 + lane, bins - 1);        // lanes past the last bin repeat it (uniform control flow), never stored
         const bool on = b0 + lane < bins;
-        const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
+        const int ph = (int)(((float)bin + 0.5f) * rpw), pw = bin - ph * p.pooled_w;     // bin / pooled_w, exact (bins < 2^16)
         mf32x2 acc[NQ][2];
 #pragma unroll
         for (int q = 0; q < NQ; q++) { acc[q][0] = mf32x2{0.f, 0.f}; acc[q][1] = mf32x2{0.f, 0.f}; }
@@ -178,7 +202,7 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
             if (c < nc) orow[(size_t)c * bins + bin] = from_f32<TOut>(res[c]);
         }
       }
-      ri = -1;
+      ri = rn; raw = rawn;
     }
     // ---- rendezvous: every wave has finished the staged image (or the run); the lowest waiting RoI names the next image ----
     if (lane == 0) { pend_idx[wv] = want >= 0 ? ri : 0x7fffffff; pend_img[wv] = want; }
@@ -193,13 +217,48 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
     // ---- stage the whole map of image `img`, channels [c0, c0 + nc): [quad][pixel][4 channels] float32 ------------------
     const TIn* src = reinterpret_cast<const TIn*>(L.data) + (int64_t)img * L.stride_n + (int64_t)c0 * L.stride_c;
     const bool rows_contig = L.stride_w == 1 && L.stride_h == W;
-    for (int e = tid; e < CG * HW; e += kMapThreads) {
-      const int c = e / HW, px = e - c * HW;
-      const int cc = min(c, nc - 1);                                  // channel tail: duplicate the last plane, never stored
-      int64_t off = (int64_t)cc * L.stride_c;
-      if (rows_contig) off += px;
-      else { const int row = px / W, col = px - row * W; off += (int64_t)row * L.stride_h + (int64_t)col * L.stride_w; }
-      mapw[((size_t)(c >> 2) * HW + px) * 4 + (c & 3)] = to_f32<TIn>(src[off]);
+    const bool vec4 = rows_contig && (HW & 3) == 0 && ((L.stride_c | L.stride_n) & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(L.data) & (4 * sizeof(TIn) - 1)) == 0;
+    constexpr int SU = 4;                                             // loads in flight per thread
+    if (vec4) {                                                       // a plane is one contiguous run: 4 pixels per load
+      const int n4 = HW >> 2, total = CG * n4;
+      for (int base = tid; base < total; base += SU * kMapThreads) {
+        float4 v[SU];
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+          const int e = min(base + u * kMapThreads, total - 1);
+          const int c = e / n4, g = e - c * n4;
+          v[u] = MapLoad4<TIn>::ld(src + (int64_t)min(c, nc - 1) * L.stride_c + 4 * g);   // channel tail: duplicate, never stored
+        }
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+          const int e = base + u * kMapThreads;
+          if (e < total) {
+            const int c = e / n4, g = e - c * n4;
+            float* d = mapw + ((size_t)(c >> 2) * HW + 4 * g) * 4 + (c & 3);
+            d[0] = v[u].x; d[4] = v[u].y; d[8] = v[u].z; d[12] = v[u].w;
+          }
+        }
+      }
+    } else {
+      const int total = CG * HW;
+      for (int base = tid; base < total; base += SU * kMapThreads) {
+        float v[SU];
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+          const int e = min(base + u * kMapThreads, total - 1);
+          const int c = e / HW, px = e - c * HW;
+          int64_t off = (int64_t)min(c, nc - 1) * L.stride_c;
+          if (rows_contig) off += px;
+          else { const int row = px / W, col = px - row * W; off += (int64_t)row * L.stride_h + (int64_t)col * L.stride_w; }
+          v[u] = to_f32<TIn>(src[off]);
+        }
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+          const int e = base + u * kMapThreads;
+          if (e < total) { const int c = e / HW, px = e - c * HW; mapw[((size_t)(c >> 2) * HW + px) * 4 + (c & 3)] = v[u]; }
+        }
+      }
     }
     __syncthreads();
     cur = img;

@@ -57,3 +57,37 @@ for lo, hi in [(0, 64), (64, 256), (256, 512), (512, 1024), (1024, 2048), (2048,
 time_subset(np.ones(len(win), bool), "all")
 time_subset(np.ones(len(win), bool), "all, largest first", order=np.argsort(-win, kind="stable"))
 time_subset(np.ones(len(win), bool), "all, smallest first", order=np.argsort(win, kind="stable"))
+
+
+def time_packed(mask, tag):
+    """the same subsets through the packed-descriptor entry (image-major order) -> the map-stationary kernel"""
+    sel = np.nonzero(mask)[0]
+    idx = valid[torch.from_numpy(sel).to(dev)]
+    rr = rois5[idx]
+    o = torch.argsort(rr[:, 0], stable=True)
+    rr = rr[o]
+    n_ = len(rr)
+    if n_ == 0:
+        return
+    desc = torch.zeros((n_, 8), device=dev)
+    desc[:, :5] = rr
+    desc[:, 6] = torch.arange(n_, device=dev, dtype=torch.float32)
+    out = torch.empty((n_, feat.shape[1], 7, 7), device=dev)
+    lvs, ch, dt = hip.make_levels([feat], [1.0 / 16])
+    call = lambda: hip.check(hip.lib().dtc_roi_align_forward_packed(lvs, 1, ch, 0, desc.data_ptr(), n_, 7, 7, 0, out.data_ptr(), 0, hip.stream_ptr()), "packed")
+    for _ in range(2):
+        call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        call()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print("  packed %-22s %5d rois: %.3f ms  (%.3f us / roi)" % (tag, n_, ms, 1e3 * ms / n_))
+
+
+print("map-stationary kernel by class:")
+for lo, hi in [(0, 64), (64, 256), (256, 512), (512, 1024), (1024, 2048), (2048, 1e9)]:
+    time_packed((win >= lo) & (win < hi), "window [%d, %d)" % (lo, hi))
+time_packed(np.ones(len(win), bool), "all")
