@@ -357,7 +357,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kern,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k_ms, 4)},
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k_ms, 4),
+                         "note": ("HBM traffic of this launch == its algorithmic bytes (every feature byte is staged once: map-stationary "
+                                  "kernel); what bounds it is the adaptive-grid gather from LDS -- ~5 samples x 4 taps per bin and channel, "
+                                  "formed with the reference's unfused multiply-adds -- i.e. VALU issue, not HBM (DESIGN 3.6)") if wl == "cfg2" else
+                                 "TCP line-fill rate / EA bandwidth of the re-fetched window rows (DESIGN 3.1)"},
             "consistency": {"timed_region_s": round(dt, 4), "gathered_equals_local": gathered_ok,
                             "sustained": None if dt_sus is None else {"steps": n_sus, "seconds": round(dt_sus, 3),
                                                                       "ms_per_step": round(dt_sus / n_sus * 1e3, 4),
