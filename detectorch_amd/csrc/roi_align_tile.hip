@@ -560,8 +560,10 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   if (kTileHdrBytes + K * bins * 16 * nq_cap + 20 * 1024 > lds_b) return DTC_EUNSUPPORTED;
   const int ngrp = ceil_div(p.n_rois, K);
   // channels per workgroup: the per-cluster setup (geometry, item registers) is paid once per block; keep >= ~4 workgroups per CU
-  int cb = cfg.ch_block ? cfg.ch_block : 64;     // measured on MI355X (8000 RoIs x 256 ch): 32 -> 0.48, 64 -> 0.41, 128 -> 0.42 ms
-  while (cb > 32 && (long long)ngrp * ceil_div(p.channels, cb) < 2048) cb >>= 1;
+  // measured on MI355X: 8000 RoIs x 256 ch (1600 groups): 32 -> 0.48, 64 -> 0.41, 128 -> 0.42 ms; 16 000 RoIs fp16 (3200 groups):
+  // 64 -> 0.568, 128 -> 0.545 ms -- the larger block as soon as it still leaves ~8 workgroups per slot
+  int cb = cfg.ch_block ? cfg.ch_block : ((long long)ngrp * ceil_div(p.channels, 128) >= 6144 ? 128 : 64);
+  while (!cfg.ch_block && cb > 32 && (long long)ngrp * ceil_div(p.channels, cb) < 2048) cb >>= 1;
   p.ch_block = cb;
   p.xcd_remap = 1;
   const int nct = ceil_div(p.channels, p.ch_block);

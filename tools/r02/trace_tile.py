@@ -59,3 +59,14 @@ wi = t[:, 15]
 for d in range(10):
     m = (wi >= d * n / 10) & (wi < (d + 1) * n / 10)
     print("  items %4.0f%%: mean %.1f us  p90 %.1f us" % (d * 10, wall[m].mean(), np.percentile(wall[m], 90)))
+# share of workgroup time by FPN level (work item wi -> cluster group wi // nct -> its 5 RoIs in visiting order)
+if not mask:
+    desc = path.roi_desc.reshape(-1, 8).cpu().numpy()
+    nct = 4
+    K = 5
+    grp = (t[:, 15] // nct).astype(np.int64)
+    lv = np.array([int(np.median(desc[g * K:(g + 1) * K, 5])) for g in grp])
+    print("share of workgroup time by level (level index 0 = P2):")
+    for l in sorted(set(lv.tolist())):
+        m = lv == l
+        print("   level %2d: %5d workgroups (%.1f %%)  time share %.1f %%  mean %.1f us" % (l, m.sum(), 100 * m.mean(), 100 * wall[m].sum() / wall.sum(), wall[m].mean()))
