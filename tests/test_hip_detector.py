@@ -81,6 +81,11 @@ def test_forward_batched_equals_reference_shaped_forward():
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     image = torch.randn(1, 3, 320, 448, generator=g, device="cuda")
     sf, im_size = torch.tensor([1.6], device="cuda"), torch.tensor([[200.0, 280.0]], device="cuda")
+    # MIOpen settles its algorithm choice during the first calls of a shape (later calls of the same shape reproduce): warm both
+    # entry points up before the compared calls, so that near-tied proposals are not swapped by conv rounding
+    model(image, scaling_factor=sf)
+    model.forward_batched(image, sf, im_size)
+    torch.cuda.synchronize()
     path = model.forward_batched(image, sf, im_size)
     torch.cuda.synchronize()
     cls_b, bbox_b, rois_b, feats_b = detector.per_image(path, 0)
