@@ -32,7 +32,8 @@
 namespace dtc {
 
 constexpr int kTileMaxK = 32;                       // RoIs per workgroup (upper bound of the K the host picks)
-constexpr int kTileHdrBytes = 2 * kTileMaxK * 32 + 16;
+constexpr int kTileRoiBytes = 48, kTileGroupBytes = 32;
+constexpr int kTileHdrBytes = kTileMaxK * (kTileRoiBytes + kTileGroupBytes) + 16;
 // Workgroup shapes (threads, 16-byte row pieces a thread carries per pass, waves per SIMD the register budget allows):
 //   256 threads x 8 pieces, 3 workgroups / CU (<= 168 VGPRs, 52 KB LDS each)   K = 5 RoIs of 7x7 bins per workgroup
 //   512 threads x 4 pieces, 2 workgroups / CU (<= 128 VGPRs, 78 KB)            K = 10
@@ -42,7 +43,11 @@ template <> struct TileShape<256> { static constexpr int kUnits = 8, kWaves = 3,
 template <> struct TileShape<512> { static constexpr int kUnits = 4, kWaves = 4, kLdsKB = 78; };
 template <> struct TileShape<1024> { static constexpr int kUnits = 4, kWaves = 4, kLdsKB = 156; };
 
-struct TileRoi { int lvl, b, x0, x1, y0, y1, r, valid; };            // window in feature pixels of its level, inclusive
+struct TileRoi {                        // 48 bytes
+  int lvl, b, x0, x1, y0, y1, r, valid;   // window in feature pixels of its level, inclusive
+  float sh, sw, bin_h, bin_w;             // scaled start and bin size (RoiHead): the item set-up reads them back from LDS
+};
+static_assert(sizeof(TileRoi) == kTileRoiBytes, "TileRoi layout");
 struct TileGroup { int first, count, kind, x0, x1, y0, y1, pad; };   // kind 0: pooled cluster, 1: zero rows, 2: absent, 3: oversize
 enum { kGrpPool = 0, kGrpZero = 1, kGrpAbsent = 2, kGrpGather = 3 };
 
@@ -321,8 +326,8 @@ template <typename TIn, typename TOut, int NT>
 __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct, int reverse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileRoi* troi = reinterpret_cast<TileRoi*>(smem);
-  TileGroup* tgrp = reinterpret_cast<TileGroup*>(smem + kTileMaxK * 32);
-  int* ngp = reinterpret_cast<int*>(smem + 2 * kTileMaxK * 32);
+  TileGroup* tgrp = reinterpret_cast<TileGroup*>(smem + kTileMaxK * kTileRoiBytes);
+  int* ngp = reinterpret_cast<int*>(smem + kTileMaxK * (kTileRoiBytes + kTileGroupBytes));
   // [header][slab: K RoIs x 4 nq_cap channels x bins float32, fixed][image: nq quads x plane slots x 16 B]
   const int slab_bytes = kgroup * p.pooled_h * p.pooled_w * 16 * nq_cap;
   float* slab = reinterpret_cast<float*>(smem + kTileHdrBytes);
@@ -344,14 +349,15 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
   const unsigned long long wall0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  // ---- A. windows of this workgroup's K RoIs (lane k) -----------------------------------------------------------------
-  if (tid < K) {
+  // ---- A + B (wavefront 0). A: lane k forms the window of RoI k.  B: greedy clustering along the visiting order, by the whole
+  // wave on the register copies (readlane with a uniform index: no LDS round trips, no barrier between A and B) ------------
+  if (tid < 64) {
     TileRoi t;
-    t.lvl = -1; t.b = 0; t.x0 = t.x1 = t.y0 = t.y1 = 0; t.r = 0; t.valid = 0;
+    t.lvl = -1; t.b = 0; t.x0 = t.x1 = t.y0 = t.y1 = 0; t.r = 0; t.valid = 0; t.sh = t.sw = 0.f; t.bin_h = t.bin_w = 1.f;
     const int ri = grp * K + tid;
-    if (ri < p.n_rois) {
+    if (tid < K && ri < p.n_rois) {
       const RoiHead hd = load_roi_head(p, ri);
-      t.valid = 1; t.r = hd.r; t.b = hd.b;
+      t.valid = 1; t.r = hd.r; t.b = hd.b; t.sh = hd.sh; t.sw = hd.sw; t.bin_h = hd.bin_h; t.bin_w = hd.bin_w;
       if (hd.lvl >= 0 && hd.lvl < p.n_levels) {
         t.lvl = hd.lvl;
         const int H = p.lv[hd.lvl].height, W = p.lv[hd.lvl].width;
@@ -362,22 +368,19 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
         t.x1 = make_axis(hd.sw, hd.bin_w, p.pooled_w - 1, 1, 2, W).hi;
       }
     }
-    troi[tid] = t;
-  }
-  __syncthreads();
-  TT_MARK(0);
-
-  // ---- B. greedy clustering along the visiting order (one lane; K <= 32 steps) ----------------------------------------
-  if (tid == 0) {
+    if (tid < K) troi[tid] = t;
+    auto bc = [](int v, int k) { return __builtin_amdgcn_readlane(v, k); };     // k: uniform lane index
     int ng = 0, k = 0;
     while (k < K) {
-      const TileRoi a = troi[k];
+      const int ks = uni(k);
+      const int a_lvl = bc(t.lvl, ks), a_b = bc(t.b, ks), a_valid = bc(t.valid, ks);
+      const int a_x0 = bc(t.x0, ks), a_x1 = bc(t.x1, ks), a_y0 = bc(t.y0, ks), a_y1 = bc(t.y1, ks);
       TileGroup g;
-      g.first = k; g.count = 1; g.x0 = a.x0; g.x1 = a.x1; g.y0 = a.y0; g.y1 = a.y1; g.pad = 0;
-      if (!a.valid) g.kind = kGrpAbsent;
-      else if (a.lvl < 0) g.kind = kGrpZero;
+      g.first = k; g.count = 1; g.x0 = a_x0; g.x1 = a_x1; g.y0 = a_y0; g.y1 = a_y1; g.pad = 0;
+      if (!a_valid) g.kind = kGrpAbsent;
+      else if (a_lvl < 0) g.kind = kGrpZero;
       else {
-        const int ngx0 = (a.x1 >> 2) - (a.x0 >> 2) + 1, th0 = a.y1 - a.y0 + 1, npos0 = th0 * ngx0;
+        const int ngx0 = (a_x1 >> 2) - (a_x0 >> 2) + 1, th0 = a_y1 - a_y0 + 1, npos0 = th0 * ngx0;
         if (npos0 > kMaxPos || (4 * npos0 + (npos0 >> 1) + 1) * 16 > win_bytes || bins > NT) {
           g.kind = kGrpGather;
         } else {
@@ -385,14 +388,16 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
           // merge the next RoI of the visiting order while the union window stays a compact patch: at most merge_pct % of the
           // pixels the members would stage one by one.  (Neighbours of the (level, band, x) order overlap about two-fold, so a
           // patch of K windows is hardly larger than their sum -- but its rows are K times longer, i.e. whole 128-byte lines.)
-          long long sum_px = (long long)th0 * (a.x1 - a.x0 + 1);
+          long long sum_px = (long long)th0 * (a_x1 - a_x0 + 1);
           while (k + g.count < K && (g.count + 1) * bins <= NT) {
-            const TileRoi n = troi[k + g.count];
-            if (!n.valid || n.lvl != a.lvl || n.b != a.b) break;
-            const int ux0 = min(g.x0, n.x0), ux1 = max(g.x1, n.x1), uy0 = min(g.y0, n.y0), uy1 = max(g.y1, n.y1);
+            const int js = uni(k + g.count);
+            const int n_lvl = bc(t.lvl, js), n_b = bc(t.b, js), n_valid = bc(t.valid, js);
+            if (!n_valid || n_lvl != a_lvl || n_b != a_b) break;
+            const int n_x0 = bc(t.x0, js), n_x1 = bc(t.x1, js), n_y0 = bc(t.y0, js), n_y1 = bc(t.y1, js);
+            const int ux0 = min(g.x0, n_x0), ux1 = max(g.x1, n_x1), uy0 = min(g.y0, n_y0), uy1 = max(g.y1, n_y1);
             const int ungx = (ux1 >> 2) - (ux0 >> 2) + 1, uth = uy1 - uy0 + 1, unpos = uth * ungx;
             if (unpos > kMaxPos || (4 * unpos + (unpos >> 1) + 1) * 16 > win_bytes) break;
-            const long long n_px = (long long)(n.y1 - n.y0 + 1) * (n.x1 - n.x0 + 1);
+            const long long n_px = (long long)(n_y1 - n_y0 + 1) * (n_x1 - n_x0 + 1);
             const long long u_px = (long long)uth * (ux1 - ux0 + 1);
             if (u_px * 100 > (sum_px + n_px) * merge_pct) break;
             g.x0 = ux0; g.x1 = ux1; g.y0 = uy0; g.y1 = uy1; g.count++;
@@ -400,12 +405,14 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
           }
         }
       }
-      tgrp[ng++] = g;
+      if (tid == 0) tgrp[ng] = g;
+      ng++;
       k += g.count;
     }
-    *ngp = ng;
+    if (tid == 0) *ngp = ng;
   }
   __syncthreads();
+  TT_MARK(0);
   TT_MARK(1);
 
   // ---- C. clusters ----------------------------------------------------------------------------------------------------
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
     const int itx = it.on ? tid : 0;
     const int rl = itx / bins, bin = itx - rl * bins;
     const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
-    const RoiHead hd = load_roi_head(p, grp * K + first + rl);
+    const TileRoi hd = troi[first + rl];     // sh / sw / bin sizes as phase A formed them
     int ylo[2], yhi[2], xlo[2], xhi[2];      // window-relative: rows premultiplied by the window width
 #pragma unroll
     for (int i = 0; i < 2; i++) {
