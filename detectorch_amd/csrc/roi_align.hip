@@ -16,15 +16,16 @@
 //
 // Kernels in this file (all produce bit-identical results; tests/test_hip_roi_align.py runs every one against the oracle):
 //   roi_align_fwd_lds      RoI-stationary: one workgroup per (RoI, channel block), window staged in LDS through a register
-//                          prefetch pipeline; stagers StagerNCHW (dword per lane), StagerNCHW2 (pixel pairs: 2-byte features),
-//                          StagerNHWC.  The path for adaptive sampling (sampling_ratio <= 0: the C4 configurations), for
-//                          sampling ratios other than 2, and the A/B partner of the cluster-stationary kernel.
+//                          prefetch pipeline; stagers StagerNCHW (dword per lane) and StagerNHWC; windows that do not fit are
+//                          pooled in slices of bin rows.  The path for multi-level inputs with sampling ratios other than 2
+//                          (incl. adaptive), channels_last 14x14, and the A/B partner of the other two RoIAlign kernels.
 //   roi_align_fwd_nhwc     channels_last features with few taps per pixel: taps gathered straight from L1/L2
 //   roi_align_fwd_general  per-output gather; oversize pooled sizes, and the plain statement of the arithmetic
-// The default for the FPN heads (NCHW features, sampling_ratio 2) is the cluster-stationary kernel in roi_align_tile.hip.
+// The default for the FPN heads (NCHW features, sampling_ratio 2) is the cluster-stationary kernel in roi_align_tile.hip,
+// for single-level inputs with adaptive sampling (the C4 heads) the map-stationary kernel in roi_align_map.hip.
 // Knobs (resolved once per process): see RoiAlignConfig below.  Variants measured slower in round 1 (wave-specialised
-// loader/compute waves, LDS-DMA staging, 16-byte row pieces, row-slot chunking, quad-aligned windows) were removed in
-// round 2; DESIGN.md section 3.1 keeps their numbers.
+// loader/compute waves, LDS-DMA staging, 16-byte row pieces, row-slot chunking, quad-aligned windows, pixel-pair loads)
+// were removed in round 2; DESIGN.md section 3.1 keeps their numbers.
 #include <stdlib.h>
 
 #include <mutex>
@@ -197,83 +198,6 @@ struct StagerNCHW {
   }
 };
 
-// NCHW, pixel-PAIR loads: lane -> (pair of neighbouring pixels in a 16-pair chunk, channel in a group of 4).  The window is
-// widened to even columns (rows of these levels start on even elements) and a lane loads both pixels with ONE instruction
-// -- a dword for fp16 / bf16, a dwordx2 for fp32 -- so a 16-lane group reads one contiguous row piece with half the lanes.
-// Measured on MI355X: fp16 NCHW 4888 -> 8336 images/s (one 2-byte load per lane makes the texture addresser issue an
-// access per lane).  The pair stays packed in registers until commit, where it becomes two float32 LDS pixels.  Lanes past
-// the window duplicate the last pair (same value to the same LDS words: benign).
-template <typename TIn> struct PairOf { using type = uint32_t; };
-template <> struct PairOf<float> { using type = float2; };
-template <typename TIn> __device__ __forceinline__ float pair_lo(uint32_t u);
-template <typename TIn> __device__ __forceinline__ float pair_hi(uint32_t u);
-template <> __device__ __forceinline__ float pair_lo<__half>(uint32_t u) { return __half2float(__ushort_as_half((unsigned short)(u & 0xffffu))); }
-template <> __device__ __forceinline__ float pair_hi<__half>(uint32_t u) { return __half2float(__ushort_as_half((unsigned short)(u >> 16))); }
-template <> __device__ __forceinline__ float pair_lo<bf16_t>(uint32_t u) { return __uint_as_float(u << 16); }
-template <> __device__ __forceinline__ float pair_hi<bf16_t>(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
-template <typename TIn> __device__ __forceinline__ float pair_lo(float2 u) { return u.x; }
-template <typename TIn> __device__ __forceinline__ float pair_hi(float2 u) { return u.y; }
-
-template <typename TIn, int K, int G>
-struct StagerNCHW2 {
-  using P = typename PairOf<TIn>::type;
-  P v[G][K];
-  uint32_t voff[K];
-  int32_t lbase[K];
-  int cl, nk, ctp;
-  int64_t stride_c;
-  // (x0, ww) already widened to even columns; wwp = ww / 2 pairs per row
-  __device__ __forceinline__ void init_window(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int cts) { init(L, y0, x0, ww, wh, cts); }
-  __device__ __forceinline__ void init(const dtc_feat_level& L, int y0, int x0, int ww, int wh, int cts) {
-    const int tid = threadIdx.x;
-    const int pl = tid & 15, wv = tid >> 6;
-    cl = (tid >> 4) & 3;
-    stride_c = L.stride_c;
-    ctp = cts + kLdsPad;
-    const int wwp = ww >> 1, npair = wh * wwp;
-    nk = ceil_div(ceil_div(npair, 16), kRoiAlignThreads / 64);
-    const float rinv = 1.0f / (float)wwp;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      const int pr = min(wv * 16 + pl + 64 * k, npair - 1);
-      const int py = (int)(((float)pr + 0.5f) * rinv);            // exact for pr < 2^12
-      const int pp = pr - py * wwp;
-      voff[k] = (uint32_t)(((int64_t)(y0 + py) * L.stride_h + (int64_t)(x0 + 2 * pp) + (int64_t)cl * L.stride_c) *
-                           (int64_t)sizeof(TIn));
-      lbase[k] = (py * ww + 2 * pp) * ctp + cl;
-    }
-  }
-  __device__ __forceinline__ void issue(const TIn* cbase, int cts, int nvalid) {
-    const char* cb = reinterpret_cast<const char*>(cbase);
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-      if (4 * g < cts) {
-        const int c = min(4 * g + cl, nvalid - 1) - cl;            // channel tail: clamp the plane, never stored
-        const char* gb = cb + (int64_t)c * stride_c * (int64_t)sizeof(TIn);
-#pragma unroll
-        for (int k = 0; k < K; k++)
-          if (k < nk) v[g][k] = *reinterpret_cast<const P*>(gb + voff[k]);
-      }
-    }
-  }
-  __device__ __forceinline__ void commit(float* win, int cts) {
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-      if (4 * g < cts) {
-#pragma unroll
-        for (int k = 0; k < K; k++)
-          if (k < nk) {
-            float* d = win + lbase[k] + 4 * g;
-            d[0] = pair_lo<TIn>(v[g][k]);
-            d[ctp] = pair_hi<TIn>(v[g][k]);
-          }
-      }
-    }
-  }
-};
-
-// NHWC (stride_c == 1): lane -> (channel quad, pixel slot); one 16-byte piece per lane, cts/4 lanes per pixel, U pixels per
-// thread (the sub-tile choice guarantees npix * cts <= 8192, so U = 8 covers every case).
 template <typename TIn>
 struct StagerNHWC {
   static constexpr int U = 8;
@@ -490,32 +414,20 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
     return;
   }
   const int y0 = ytab[0].lo, y1 = ytab[ny - 1].hi, x1 = xtab[nx - 1].hi;
-  int x0 = xtab[0].lo;
-  int ww = x1 - x0 + 1;
+  const int x0 = xtab[0].lo;
+  const int ww = x1 - x0 + 1;
   const int wh = y1 - y0 + 1;
   // the tables take what this RoI needs (28 entries for 7x7 bins x 2 samples), not the 4 KB worst case: ~3.5 KB more window
   const int tabf = ((ny + nx) * 4 + 15) & ~15;
   const int avail = lds_floats - tabf;
-  // pixel-pair loads (StagerNCHW2) when rows start on even elements: dword pairs for fp16/bf16, dwordx2 pairs for fp32
-  const bool pairs = p.pair_loads && (sizeof(TIn) == 2 || p.pair_loads > 1) && L.stride_c != 1 && L.stride_w == 1 &&
-                     ((L.width | L.stride_h | L.stride_c | L.stride_n) & 1) == 0 &&
-                     (reinterpret_cast<uintptr_t>(L.data) & (2 * sizeof(TIn) - 1)) == 0;
-  const int pair_budget = sizeof(TIn) == 2 ? 8192 : 4096;   // pairs x channels a workgroup holds in 32 registers per thread
-  if (pairs) {
-    x0 = x0 & ~1;
-    ww = ((x1 >> 1) - (x0 >> 1) + 1) * 2;
-  }
   // sub-tile width: largest CTs whose window of wh_ rows (+1 dummy pixel) + output slab fit; one dword per lane, the
   // per-thread share of the window must fit the 32 prefetch registers (npix * cts <= 8192)
   auto pick_cts = [&](int wh_) -> int {
     const int np = wh_ * ww;
-    if (p.cts64 && pairs && nc >= 64 && (np / 2) * 64 <= pair_budget &&
-        (long long)(np + 1) * (64 + kLdsPad) + 64LL * bins <= avail) return 64;
-    if (p.cts64 && !pairs && L.stride_c != 1 && nc >= 64 && np <= 128 &&
+    if (p.cts64 && L.stride_c != 1 && nc >= 64 && np <= 128 &&
         (long long)(np + 1) * (64 + kLdsPad) + 64LL * bins <= avail) return 64;
     for (int c = 32; c >= 8; c >>= 1)
-      if (np <= kLdsMaxPix * (pairs ? 2 : 1) && (pairs ? (np / 2) * c <= pair_budget : np * c <= 8192) &&
-          (long long)(np + 1) * (c + kLdsPad) + (long long)c * bins <= avail) return c;
+      if (np <= kLdsMaxPix && np * c <= 8192 && (long long)(np + 1) * (c + kLdsPad) + (long long)c * bins <= avail) return c;
     return 0;
   };
   int cts = pick_cts(wh);
@@ -581,10 +493,7 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
   G.rows = rows; G.pooled_h = p.pooled_h; G.x0 = x0; G.ww = ww; G.y0 = y0; G.wh = wh; G.height = L.height;
   G.sh = sh; G.bin_h = bin_h; G.bin0 = 0; G.nb = bins;
   if (rows != p.pooled_h) {        // sliced: the largest register pipeline of the layout, one instantiation
-    if (pairs) {
-      if constexpr (sizeof(TIn) == 2) { StagerNCHW2<TIn, 16, 2> st; run_passes<TIn, TOut, true>(st, G, L, cbase, L.stride_c, out); }
-      else { StagerNCHW2<TIn, 8, 2> st; run_passes<TIn, TOut, true>(st, G, L, cbase, L.stride_c, out); }
-    } else if (L.stride_c == 1) {
+    if (L.stride_c == 1) {
       StagerNHWC<TIn> st;
       run_passes<TIn, TOut, true>(st, G, L, cbase, L.stride_c, out);
     } else {
@@ -593,22 +502,7 @@ __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_
     }
     return;
   }
-  if (pairs) {
-    const int nkp = ceil_div(ceil_div(npix_max / 2, 16), kRoiAlignThreads / 64);
-#define DTC_RUN2(KK, GG) { StagerNCHW2<TIn, KK, GG> st; run_passes<TIn, TOut, false>(st, G, L, cbase, L.stride_c, out); }
-    if constexpr (sizeof(TIn) == 2) {
-      if (cts == 64) DTC_RUN2(2, 16)
-      else if (nkp <= 4) DTC_RUN2(4, 8)
-      else if (nkp <= 8) DTC_RUN2(8, 4)
-      else DTC_RUN2(16, 2)
-    } else {
-      if (cts == 64) DTC_RUN2(1, 16)
-      else if (nkp <= 2) DTC_RUN2(2, 8)
-      else if (nkp <= 4) DTC_RUN2(4, 4)
-      else DTC_RUN2(8, 2)
-    }
-#undef DTC_RUN2
-  } else if (L.stride_c == 1) {
+  if (L.stride_c == 1) {
     StagerNHWC<TIn> st;
     run_passes<TIn, TOut, false>(st, G, L, cbase, L.stride_c, out);
   } else {
@@ -764,10 +658,10 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
 //   DTC_ROIALIGN_MAP=0           single-level inputs (C4) through the RoI-stationary kernel instead of the map-stationary one (roi_align_map.hip)
 //   DTC_ROIALIGN_GENERAL=1       force the per-output gather kernel (the plain statement of the arithmetic)
 //   DTC_ROIALIGN_NO_NHWC_DIRECT  channels_last features through the LDS-staged kernel
-//   DTC_ROIALIGN_LDS_KB (52)  DTC_RA_CHBLOCK (128 / 64)  DTC_RA_NO_XCD  DTC_RA_NO_CTS64  DTC_RA_NO_PAIRS  DTC_RA_PAIRS32
+//   DTC_ROIALIGN_LDS_KB (52)  DTC_RA_CHBLOCK (128 / 64)  DTC_RA_NO_XCD  DTC_RA_NO_CTS64
 struct RoiAlignConfig {
   bool tile = true, map = true, general = false, nhwc_direct = true, xcd = true, cts64 = true;
-  int pair_loads = 1, ch_block = 0, lds_bytes = 52 * 1024;
+  int ch_block = 0, lds_bytes = 52 * 1024;
 };
 static const RoiAlignConfig& roi_align_config() {
   static const RoiAlignConfig cfg = [] {
@@ -778,8 +672,6 @@ static const RoiAlignConfig& roi_align_config() {
     c.nhwc_direct = getenv("DTC_ROIALIGN_NO_NHWC_DIRECT") == nullptr;
     c.xcd = getenv("DTC_RA_NO_XCD") == nullptr;
     c.cts64 = getenv("DTC_RA_NO_CTS64") == nullptr;      // 64-channel sub-tiles for windows <= 128 px: +4 % on the bench workload
-    // 1: pixel-pair loads for 2-byte features; 2 (DTC_RA_PAIRS32=1): for fp32 features too (dwordx2 per lane, measured slower)
-    c.pair_loads = getenv("DTC_RA_NO_PAIRS") != nullptr ? 0 : (getenv("DTC_RA_PAIRS32") != nullptr ? 2 : 1);
     if (const char* e = getenv("DTC_RA_CHBLOCK")) { const int v = atoi(e); if (v >= 64 && v % 64 == 0) c.ch_block = v; }
     if (const char* e = getenv("DTC_ROIALIGN_LDS_KB")) { const int v = atoi(e); if (v >= 16 && v <= 160) c.lds_bytes = v * 1024; }
     return c;
@@ -873,7 +765,7 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   p.ch_block = channels > 64 ? 128 : 64;
   if ((long long)n_rois * ((channels + p.ch_block - 1) / p.ch_block) < 3072) p.ch_block = 64;
   if (cfg.ch_block) p.ch_block = cfg.ch_block;
-  p.xcd_remap = cfg.xcd; p.cts64 = cfg.cts64; p.pair_loads = cfg.pair_loads;
+  p.xcd_remap = cfg.xcd; p.cts64 = cfg.cts64;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // LDS-staged kernel for every pooled size whose output slab fits; adaptive sampling (sampling_ratio <= 0) included
   // (tables sized per RoI, oversize grids / windows fall back per workgroup)

@@ -16,7 +16,6 @@ struct RoiAlignParams {
   void* out;
   int n_levels, channels, roi_cols, n_rois, pooled_h, pooled_w, sampling_ratio, ch_tile;
   int ch_block;   // channels per workgroup of the LDS kernel (multiple of 64): setup (tables, window) is paid once per block
-  int pair_loads; // 1: 2-byte features are gathered as pixel pairs (StagerNCHW2)
   int cts64;      // 1: allow 64-channel sub-tiles (one bin per ds_read_b128 lane group: conflict-free taps)
   int xcd_remap;  // 1: workgroup -> work-item mapping keeps each XCD on a contiguous range of the visiting order
 };
