@@ -315,11 +315,11 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
 // largest windows and merge least (3-4 clusters per workgroup, 2-2.5 x the average duration).  Started last they were the
 // tail of the launch (no workgroup starts during its last 20 %); started first the tail is made of average workgroups.
 __device__ __forceinline__ int tile_work_item(int b, int n, int reverse) {
-  if (n < 2 * kXcds) return reverse ? n - 1 - b : b;
+  if (n < 2 * kXcds || (reverse & 2)) return (reverse & 1) ? n - 1 - b : b;      // bit 1: no XCD slicing (A/B knob DTC_RA_NO_XCD)
   const int x = b % kXcds, j = b / kXcds;
   const int q = n / kXcds, r = n - q * kXcds;
   const int start = x * q + min(x, r), qx = q + (x < r ? 1 : 0);
-  return start + (reverse ? qx - 1 - j : j);
+  return start + ((reverse & 1) ? qx - 1 - j : j);
 }
 
 template <typename TIn, typename TOut, int NT>
@@ -572,9 +572,8 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   int cb = cfg.ch_block ? cfg.ch_block : ((long long)ngrp * ceil_div(p.channels, 128) >= 6144 ? 128 : 64);
   while (!cfg.ch_block && cb > 32 && (long long)ngrp * ceil_div(p.channels, cb) < 2048) cb >>= 1;
   p.ch_block = cb;
-  p.xcd_remap = 1;
   const int nct = ceil_div(p.channels, p.ch_block);
-  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, cfg.reverse ? 1 : 0);
+  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, (cfg.reverse ? 1 : 0) | (p.xcd_remap ? 0 : 2));
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }
