@@ -168,6 +168,11 @@ def roi_align_forward(features, spatial_scales, rois, pooled_h, pooled_w, sampli
     if rois.dtype != torch.float32:
         raise TypeError("rois must be float32")
     rois = rois.contiguous()
+    if (len(features) == 1 and features[0].shape[0] == 1 and rois.dim() == 2 and rois.shape[1] == 5 and rois.shape[0] > 0
+            and roi_levels is None):
+        # one image: the batch column can only hold 0 (lib/cppcuda/roi_align_cpu.cpp:143-147 indexes the batch with it), so the
+        # RoIs go down as 4 columns -- which tells the library that they all belong to one map (map-stationary kernel for C4)
+        rois = rois[:, 1:].contiguous()
     R, cols = (rois.shape[0], rois.shape[1]) if rois.dim() == 2 else (0, 5)
     lv, ch, dt = make_levels(features, spatial_scales)
     odt = out_dtype or (out.dtype if out is not None else torch.float32)

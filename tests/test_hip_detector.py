@@ -8,6 +8,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _deterministic_convs():
+    """MIOpen's default conv algorithms are not reproducible from call to call (feature maps differ by ~3e-7 between two
+    forward passes of the same input, measured: tools/r02/dbg_det.py), which can swap near-tied proposals between the two
+    flows these tests compare.  The deterministic algorithms reproduce bit for bit."""
+    old = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    yield
+    torch.backends.cudnn.deterministic = old
+
+
 def _fpn_model(arch="resnet50", channels_last=False):
     from detectorch_amd.model.detector import detector
     torch.manual_seed(0)
@@ -81,11 +92,6 @@ def test_forward_batched_equals_reference_shaped_forward():
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     image = torch.randn(1, 3, 320, 448, generator=g, device="cuda")
     sf, im_size = torch.tensor([1.6], device="cuda"), torch.tensor([[200.0, 280.0]], device="cuda")
-    # MIOpen settles its algorithm choice during the first calls of a shape (later calls of the same shape reproduce): warm both
-    # entry points up before the compared calls, so that near-tied proposals are not swapped by conv rounding
-    model(image, scaling_factor=sf)
-    model.forward_batched(image, sf, im_size)
-    torch.cuda.synchronize()
     path = model.forward_batched(image, sf, im_size)
     torch.cuda.synchronize()
     cls_b, bbox_b, rois_b, feats_b = detector.per_image(path, 0)
