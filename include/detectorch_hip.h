@@ -73,7 +73,12 @@ int dtc_roi_align_forward_ordered(const dtc_feat_level* levels, int n_levels, in
 
 /* Same, driven by packed descriptors: roi_desc float32 [R,8] = (batch, x1, y1, x2, y2, level, output_row, 0), one row per
  * workgroup in visiting order (level < 0: padding row, its output row is zero-filled).  Saves the three dependent global
- * loads (order -> level -> roi) at the head of every workgroup. */
+ * loads (order -> level -> roi) at the head of every workgroup.
+ * Kernel selection (all produce bit-identical results): sampling_ratio 2 on NCHW maps -> cluster-stationary kernel; ONE level
+ * whose whole map of 8 channels fits LDS (H*W <= ~4900 pixels: the C4 heads) with any other sampling ratio -> map-stationary
+ * kernel, which stages the map of an image once per run of RoIs and therefore wants the descriptors IMAGE-MAJOR (what
+ * dtc_fpn_collect_distribute emits; any order is correct, every change of image re-stages the map).  The plain entries take the
+ * map-stationary kernel only for 4-column RoIs (one image). */
 int dtc_roi_align_forward_packed(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,
                                  const float* roi_desc, int n_rois, int pooled_h, int pooled_w, int sampling_ratio, void* out,
                                  int out_dtype, dtc_stream_t stream);
