@@ -68,7 +68,9 @@ class DetectionGatherer:
         self._turn = 1 - s
 
     def finish(self):
-        """Wait for the outstanding gathers; returns (all_dets [W,imgs,max_out,6], all_counts int32 [W,imgs]) of the last step."""
+        """Wait for the outstanding gathers; returns (all_dets [W,imgs,max_out,6], all_counts int32 [W,imgs]) of the last step.
+        all_counts are the TRUE per-image counts (dtc_postprocess_detections: they exceed max_out when scores tie at the image
+        threshold or max_det <= 0); the rows that hold data are `self.n_valid` = min(count, max_out)."""
         for w in self._work:
             if w is not None:
                 w.wait()
@@ -76,6 +78,7 @@ class DetectionGatherer:
         a = self._all[self._last]
         self.all_dets = a[:, :, :-1].reshape(self.all_dets.shape)
         self.all_counts = a[:, :, -1:].view(torch.int32).reshape(a.shape[0], a.shape[1]).clone()
+        self.n_valid = self.all_counts.clamp(max=self.all_dets.shape[2])
         return self.all_dets, self.all_counts
 
 
@@ -116,7 +119,7 @@ class ResultGatherer:
         return self.finish()
 
     def finish(self):
-        """-> dict(dets [W*per, D, 6], det_count [W*per], im_size [W*per, 2], rle_len [W*per, D], rle_str [W*per, D, stride]) in
+        """-> dict(dets [W*per, D, 6], det_count [W*per], n_valid [W*per] = min(det_count, D), im_size [W*per, 2], rle_len [W*per, D], rle_str [W*per, D, stride]) in
         (rank, local image) order; use unshard_order() to put the images back in dataset order."""
         a, D, n = self.all.reshape(-1, self.width), self.D, self.world * self.per
         out = dict(dets=a[:, :self.o_cnt].contiguous().view(torch.float32).reshape(n, D, 6),
@@ -124,5 +127,6 @@ class ResultGatherer:
                    im_size=a[:, self.o_sz:self.o_len].contiguous().view(torch.float32).reshape(n, 2),
                    rle_len=a[:, self.o_len:self.o_str].contiguous().view(torch.int32).reshape(n, D),
                    rle_str=a[:, self.o_str:].reshape(n, D, self.stride))
+        out["n_valid"] = out["det_count"].clamp(max=D)     # det_count is the true count; only max_out rows carry data
         out["truncated"] = bool((out["rle_len"] > self.stride).any())
         return out
