@@ -280,12 +280,14 @@ def main():
 
     for _ in range(NSETS):                   # eager pass + hipGraph capture of every path BEFORE the first collective is
         pipe.step(use_graph=not a.eager)     # issued: no stream capture ever overlaps RCCL work in flight
+    pipe.synchronize()
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     pipe.count = 0
     for _ in range(max(a.warmup, NSETS)):
         one_step()
+    pipe.synchronize()
     if gather is not None:
         gather.finish()
     pipe.count = 0

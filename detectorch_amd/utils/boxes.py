@@ -25,12 +25,24 @@ def _dev():
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def nms(dets, thresh):
-    """Apply classic DPM-style greedy NMS (boxes.py:332).  dets: ndarray [N,5] -> ndarray int64 of kept indices."""
+def nms(dets, thresh, tie_break='index_asc'):
+    """Apply classic DPM-style greedy NMS (boxes.py:332).  dets: ndarray [N,5] -> ndarray int64 of kept indices.
+
+    tie_break: visiting order of boxes with EQUAL scores.  The reference visits `scores.argsort()[::-1]`
+    (cython_nms.pyx:45): the reverse of an ascending argsort, i.e. equal scores in DESCENDING index order whenever numpy's
+    sort happens to be stable (it is unspecified for the default kind).  'index_asc' (default) is this library's canonical
+    rule everywhere (score desc, index asc); 'index_desc' reproduces the stable-argsort reading of the reference -- done on
+    the host by running the same kernel on the row-reversed array and mapping the kept indices back."""
     if dets.shape[0] == 0:
         return []                                              # boxes.py:334-335
-    d = torch.from_numpy(np.ascontiguousarray(dets, dtype=np.float32)).to(_dev())
-    return hip.nms(d, thresh).cpu().numpy()
+    assert tie_break in ('index_asc', 'index_desc')
+    a = np.ascontiguousarray(dets, dtype=np.float32)
+    if tie_break == 'index_desc':
+        a = np.ascontiguousarray(a[::-1])
+    keep = hip.nms(torch.from_numpy(a).to(_dev()), thresh).cpu().numpy()
+    if tie_break == 'index_desc':
+        keep = np.sort(a.shape[0] - 1 - keep)
+    return keep
 
 
 def soft_nms(dets, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, method='linear'):

@@ -135,3 +135,45 @@ def test_box_results_soft_nms_branch(hip, oracle):
         rd, _ = oracle.soft_nms(dj, 0.5, 0.5, 0.0001, "linear") if len(inds) else (dj, [])
         n += rd.shape[0]
     assert n >= sc.shape[0] >= 100
+
+
+def _greedy_nms(dets, thresh, order):
+    """cython_nms.pyx:37-87 with an explicit visiting order (float32 arithmetic, `>=`)."""
+    x1, y1, x2, y2 = (dets[:, k] for k in range(4))
+    areas = (x2 - x1 + np.float32(1)) * (y2 - y1 + np.float32(1))
+    sup = np.zeros(len(dets), bool)
+    for _i, i in enumerate(order):
+        if sup[i]:
+            continue
+        for j in order[_i + 1:]:
+            if sup[j]:
+                continue
+            w = max(np.float32(0), min(x2[i], x2[j]) - max(x1[i], x1[j]) + np.float32(1))
+            h = max(np.float32(0), min(y2[i], y2[j]) - max(y1[i], y1[j]) + np.float32(1))
+            inter = np.float32(w * h)
+            if inter / np.float32(areas[i] + areas[j] - inter) >= np.float32(thresh):
+                sup[j] = True
+    return np.where(~sup)[0]
+
+
+def test_tie_break_orders(hip):
+    """ADVICE r1: the reference visits scores.argsort()[::-1] (cython_nms.pyx:45) -- equal scores in descending index order
+    when the argsort is stable.  utils.boxes.nms(tie_break='index_desc') reproduces that reading, the default keeps the
+    canonical (score desc, index asc); with tied scores the two keep sets differ, each equals a greedy NMS run in its order."""
+    from detectorch_amd.utils import boxes as bu
+    rs = synth.rng(7, 11)
+    n = 300
+    dets = np.zeros((n, 5), np.float32)
+    dets[:, :4] = synth.make_rois(rs, n)
+    dets[:, 4] = rs.randint(0, 6, n).astype(np.float32) / 8          # six distinct scores: ~50 boxes tie on each
+    dets[::3, :4] = dets[1::3, :4][:len(dets[::3])]                  # identical boxes with (often) identical scores
+    asc = np.lexsort((np.arange(n), -dets[:, 4]))                    # score desc, index asc
+    desc = np.argsort(dets[:, 4], kind='stable')[::-1]               # what a stable argsort makes of cython_nms.pyx:45
+    k_asc = bu.nms(dets, 0.5)
+    k_desc = bu.nms(dets, 0.5, tie_break='index_desc')
+    assert np.array_equal(k_asc, _greedy_nms(dets, 0.5, list(asc)))
+    assert np.array_equal(k_desc, _greedy_nms(dets, 0.5, list(desc)))
+    assert not np.array_equal(k_asc, k_desc)
+    # tie-free input: the option changes nothing
+    dets[:, 4] = rs.permutation(n).astype(np.float32)
+    assert np.array_equal(bu.nms(dets, 0.5), bu.nms(dets, 0.5, tie_break='index_desc'))
