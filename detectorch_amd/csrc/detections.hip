@@ -13,6 +13,7 @@
 #include "radix_select.h"
 
 namespace dtc {
+DTC_PT_TABLE(detections)
 
 constexpr int kDetThreads = 256;
 
@@ -88,6 +89,8 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
   const float* sc = p.cls_score + (size_t)b * p.R * p.n_cls + j;
   int32_t* qroi = p.q_roi + (size_t)seg * p.R;
   float* qs = p.q_scores + (size_t)seg * p.R;
+  [[maybe_unused]] const int ptb = blockIdx.y * gridDim.x + blockIdx.x;
+  DTC_PT(0, ptb, 0);
   if (tid == 0) running = 0;
   __syncthreads();
   // ordered compaction of {r : scores[r, j] > thresh}  (np.where, result_utils.py:127)
@@ -119,10 +122,12 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
   }
   const int n = running;
   if (tid == 0) p.cand_count[seg] = n;
+  DTC_PT(0, ptb, 1);
   if (n == 0) return;
   const int np2 = next_pow2(n);
   for (int i = n + tid; i < np2; i += kDetThreads) keys[i] = kPadKey;
   block_bitonic_sort<kDetThreads>(keys, np2);
+  DTC_PT(0, ptb, 2);
   // decode candidate q (once), then emit both the candidate-order and the score-order copies
   const float sf = p.scale[b];
   const float im_h = p.im_size[b * 2 + 0], im_w = p.im_size[b * 2 + 1];
@@ -137,6 +142,7 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
     qb[q] = make_float4(o[0], o[1], o[2], o[3]);
   }
   __syncthreads();
+  DTC_PT(0, ptb, 3);
   float4* sb = reinterpret_cast<float4*>(p.sorted_boxes) + (size_t)seg * p.R;
   int32_t* qk = p.q_of_k + (size_t)seg * p.R;
   for (int k = tid; k < n; k += kDetThreads) {
@@ -144,6 +150,7 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
     qk[k] = q;
     sb[k] = qb[q];
   }
+  DTC_PT(0, ptb, 4);
 }
 
 constexpr int kFinThreads = 1024;
@@ -167,7 +174,7 @@ struct FinParams {
 constexpr int kFinStage = 6144;   // kept entries staged in LDS (ordered score + class/candidate id); more -> global path
 
 __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) {
-  __shared__ uint32_t h[2048];
+  __shared__ __attribute__((aligned(16))) uint32_t h[2048];
   __shared__ uint32_t sh[2];
   __shared__ int koff[kFinMaxCls + 1];
   __shared__ int ccnt[kFinMaxCls];
@@ -178,6 +185,7 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nseg = p.n_cls - 1;
   const int seg0 = b * nseg;
+  DTC_PT(1, b, 0);
   if (tid < nseg) ccnt[tid] = p.keep_count[seg0 + tid];
   __syncthreads();
   if (tid == 0) {
@@ -204,6 +212,7 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
     }
     __syncthreads();
   }
+  DTC_PT(1, b, 1);
   // ---- per-image limit (result_utils.py:154-163): threshold = max_det-th largest kept score ----
   uint32_t T = 0;  // ordered-key threshold; 0 == keep everything
   if (p.max_det > 0 && total > p.max_det) {
@@ -233,6 +242,7 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
   }
   // ---- pass A: survivors per class ----
   __syncthreads();
+  DTC_PT(1, b, 2);
   for (int c = wv; c < nseg; c += kFinThreads / 64) {
     const int nk = koff[c + 1] - koff[c];
     int cnt = 0;
@@ -249,6 +259,7 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
     if (lane == 0) ccnt[c] = cnt;
   }
   __syncthreads();
+  DTC_PT(1, b, 3);
   if (tid == 0) {
     int acc = 0;
     for (int c = 0; c < nseg; c++) { coff[c] = acc; acc += ccnt[c]; }
@@ -256,6 +267,7 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
     p.det_count[b] = acc;
   }
   __syncthreads();
+  DTC_PT(1, b, 4);
   // ---- pass B: class-major, candidate(roi)-ascending output (:143 dets_j[keep], :165 vstack) ----
   const float sf = p.scale[b];
   for (int c = wv; c < nseg; c += kFinThreads / 64) {
@@ -301,6 +313,7 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
     }
     __builtin_amdgcn_wave_barrier();
   }
+  DTC_PT(1, b, 5);
 }
 
 static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }

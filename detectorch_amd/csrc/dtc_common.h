@@ -55,6 +55,28 @@ __device__ __forceinline__ float4 bf16x4_to_f32(uint2 r) {
 
 __host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Development aid (-DDTC_PHASE_TRACE, tools/r02b/phase_trace.py): thread 0 of the first workgroups of an instrumented kernel
+// stamps the 100 MHz wall clock at its phase boundaries into a per-file table [kernel id][workgroup][mark] that
+// dtc_debug_phase_trace_<file>() copies out.  Compiled out of the product (the macros expand to nothing).
+#ifdef DTC_PHASE_TRACE
+constexpr int kPtKernels = 4, kPtBlocks = 64, kPtMarks = 24;
+#define DTC_PT_TABLE(name)                                                                                         \
+  static __device__ unsigned long long g_pt[dtc::kPtKernels * dtc::kPtBlocks * dtc::kPtMarks];                    \
+  }                                                                                                                \
+  DTC_API int dtc_debug_phase_trace_##name(void* dst, size_t bytes) {                                              \
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(dtc::g_pt), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; \
+  }                                                                                                                \
+  namespace dtc {
+#define DTC_PT(kid, blk, mark)                                                                                     \
+  do {                                                                                                             \
+    if (threadIdx.x == 0 && (blk) < dtc::kPtBlocks)                                                                \
+      dtc::g_pt[((kid) * dtc::kPtBlocks + (blk)) * dtc::kPtMarks + (mark)] = __builtin_amdgcn_s_memrealtime();    \
+  } while (0)
+#else
+#define DTC_PT_TABLE(name)
+#define DTC_PT(kid, blk, mark) ((void)0)
+#endif
+
 // Zero-fill as a KERNEL node.  hipMemsetAsync must not be used on any path that can be captured into a hipGraph: on ROCm
 // 7.0 / gfx950 a captured memset node followed by kernels that are ALSO launched eagerly between replays was observed to
 // run out of order with them (round 2: stale radix-select histograms after `replay B, eager A, eager B, replay A`).

@@ -13,6 +13,7 @@
 #include "dtc_common.h"
 
 namespace dtc {
+DTC_PT_TABLE(fpn)
 
 constexpr int kFpnThreads = 1024;
 constexpr int kFpnMaxLevels = 8;
@@ -251,17 +252,23 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(Fpn
 // the owner straight to its sorted slot.  Measured on MI355X (batch 8, 5 x 1000 -> 1000): 51 -> see profiles/r02_*.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kFastMaxTop = 1024;
+constexpr int kOrderBuckets = 512;     // visiting-order key >> 23 = (level:3 | band:6)
+constexpr int kFastHdrBytes = 2 * kFastMaxTop * 4 + 2 * kOrderBuckets * 4;
 
 __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams p, int n_max) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* k32 = reinterpret_cast<uint32_t*>(smem);                       // [1024]  order keys (later)
+  uint32_t* k32 = reinterpret_cast<uint32_t*>(smem);                       // [1024]  order keys, bucket by bucket (later)
   int* src_of_rank = reinterpret_cast<int*>(smem) + kFastMaxTop;             // [1024]
-  uint64_t* kbuf = reinterpret_cast<uint64_t*>(smem + 2 * kFastMaxTop * 4);  // [2 * n_max] input keys, then merge outputs
+  uint32_t* bstart = reinterpret_cast<uint32_t*>(smem) + 2 * kFastMaxTop;    // [512]   visiting order: bucket histogram -> start
+  uint32_t* bcur = bstart + kOrderBuckets;                                   // [512]   members placed so far
+  uint64_t* kbuf = reinterpret_cast<uint64_t*>(smem + kFastHdrBytes);        // [2 * n_max] input keys, then merge outputs
+  __shared__ uint32_t bwsum[kOrderBuckets / 64];
   __shared__ int cnt_s[kFpnMaxLevels];
   __shared__ int l_off[kFpnMaxLevels], l_len[kFpnMaxLevels];
   __shared__ int wave_cnt[kFpnMaxLevels][kFpnThreads / 64];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nl_out = p.k_max - p.k_min + 1;
+  DTC_PT(p.L_in > 1 ? 0 : 1, b, 0);
   if (tid < p.L_in) cnt_s[tid] = min(p.in_counts[b * p.L_in + tid], p.P);
   __syncthreads();
   int in_off[kFpnMaxLevels + 1];
@@ -322,6 +329,7 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams
     if (tid < m) src_of_rank[tid] = (int)desc_key_index(kbuf[l_off[0] + tid]);
     __syncthreads();
   }
+  DTC_PT(p.L_in > 1 ? 0 : 1, b, 1);
   // ---- rank r: roi, level, position inside its level -- all in registers from here on ---------------------------------
   const int r = tid;
   int lvl = -1;
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams
     key = (min(lv4, 7u) << 29) | (((band << 12) | xf) << 11) | (uint32_t)r;
   }
   __syncthreads();                                                             // src_of_rank / sc reads done; wave_cnt complete
-  k32[tid] = key;
+  if (tid < kOrderBuckets) { bstart[tid] = 0u; bcur[tid] = 0u; }
   int lvl_tot[kFpnMaxLevels], dst = -1;
   {
     int acc = 0, base = 0;
@@ -379,14 +387,36 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams
   if (tid == 0) p.n_out[b] = m;
   if (!p.roi_order) return;
   __syncthreads();
-  // rank by counting (keys are unique): 16-byte broadcast LDS reads, 4 keys each; entries past top_n are 0xffffffff
-  if (r < p.top_n) {
-    const int n4 = (p.top_n + 3) >> 2;
-    int rank = 0;
-    for (int j = 0; j < n4; j++) {
-      const uint4 q = reinterpret_cast<const uint4*>(k32)[j];
-      rank += (q.x < key ? 1 : 0) + (q.y < key ? 1 : 0) + (q.z < key ? 1 : 0) + (q.w < key ? 1 : 0);
-    }
+  DTC_PT(p.L_in > 1 ? 0 : 1, b, 2);
+  // Rank of this RoI's key among all keys (they are unique).  Round 2 counted `key' < key` over ALL top_n keys per thread
+  // (250 broadcast ds_read_b128 + 1000 compares each: the longest phase of the kernel); the key's top 9 bits (level | band)
+  // name one of a few dozen populated buckets of ~75 RoIs, so: histogram -> exclusive scan -> members placed bucket by
+  // bucket (any order) -> each thread counts the smaller keys of ITS bucket only.  rank = bucket start + that count.
+  const bool valid = r < p.top_n;
+  const uint32_t bucket = key >> 23;
+  if (valid) atomicAdd(&bstart[bucket], 1u);
+  __syncthreads();
+  uint32_t hv = 0, incl = 0;
+  if (tid < kOrderBuckets) {
+    hv = bstart[tid]; incl = hv;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+    if (lane == 63) bwsum[wv] = incl;
+  }
+  __syncthreads();
+  if (tid < kOrderBuckets) {
+    uint32_t base = 0;
+    for (int q = 0; q < wv; q++) base += bwsum[q];
+    bstart[tid] = base + incl - hv;
+  }
+  __syncthreads();
+  uint32_t start = 0;
+  if (valid) { start = bstart[bucket]; k32[start + atomicAdd(&bcur[bucket], 1u)] = key; }
+  __syncthreads();
+  if (valid) {
+    const int cnt = (int)bcur[bucket];
+    int rank = (int)start;
+    for (int j = 0; j < cnt; j++) rank += k32[start + j] < key ? 1 : 0;
     const size_t g = (size_t)b * p.top_n + rank;
     p.roi_order[g] = b * p.top_n + r;
     if (p.roi_desc) {
@@ -395,6 +425,7 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams
       d[1] = make_float4(bx.w, (float)lvl, (float)(b * p.top_n + r), 0.f);
     }
   }
+  DTC_PT(p.L_in > 1 ? 0 : 1, b, 3);
 }
 
 }  // namespace dtc
@@ -436,8 +467,8 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
   const bool fast = post_nms_top_n <= dtc::kFastMaxTop && in_stride <= 1024 && n_max <= 8192 &&
                     (!in_scores || inputs_sorted) && !no_fast;
   if (fast) {
-    // k32 + src_of_rank (8 KB) + input keys (n_max) + merge outputs (<= n_max): 8 B each
-    const size_t fsm = (size_t)2 * dtc::kFastMaxTop * 4 + (size_t)(in_scores && n_in_levels > 1 ? 2 * n_max : 0) * 8 + 16;
+    // k32 + src_of_rank + order buckets (12 KB) + input keys (n_max) + merge outputs (<= n_max): 8 B each
+    const size_t fsm = (size_t)dtc::kFastHdrBytes + (size_t)(in_scores && n_in_levels > 1 ? 2 * n_max : 0) * 8 + 16;
     static std::once_flag once;
     static hipError_t arc = hipSuccess;
     std::call_once(once, [] { arc = hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::fpn_collect_fast_kernel),

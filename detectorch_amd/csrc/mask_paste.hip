@@ -18,8 +18,9 @@ namespace dtc {
 
 constexpr int kPasteThreads = 256;
 constexpr int kMaxMaskSide = 64;  // M + 2 <= 64
-constexpr int kPasteSplit = 8;    // workgroups per detection (row bands): one huge box no longer sets the kernel's duration
-constexpr int kMaxTab = 4096;     // paste rectangle width + height served from LDS tables (larger: per-pixel math)
+constexpr int kPasteSplit = 8;    // workgroups per detection, at most (row bands): one huge box does not set the kernel's duration
+constexpr int kBandPixels = 4096; // a detection uses ceil(area / kBandPixels) of its kPasteSplit workgroups; the others exit at once
+constexpr int kMaxTab = 2048;     // paste rectangle width + height served from LDS tables (larger: per-pixel math)
 
 struct PasteParams {
   const float* masks;         // [n_masks, n_cls, M, M]
@@ -63,36 +64,49 @@ __device__ __forceinline__ void resize_axis(int dd, double scale, int S, int& s0
   s1 = min(s0 + 1, S - 1);
 }
 
+// LDS: [ (M+2)^2 mask | kMaxTab int | kMaxTab float ] = 20 KB at M = 28 -> eight workgroups per CU.  (Round 1/2 kept 48 KB of
+// static tables, i.e. three workgroups per CU, and ran the full set-up in all kPasteSplit x max_out x B workgroups: 8192
+// workgroups in 11 rounds = 43 us for 2.6 MB of output.  Now a workgroup that has nothing to paste leaves after one load.)
 __global__ __launch_bounds__(kPasteThreads) void mask_paste_kernel(PasteParams p) {
-  __shared__ float pm[kMaxMaskSide * kMaxMaskSide];
-  __shared__ int tab_i[kMaxTab];
-  __shared__ float tab_f[kMaxTab];
+  extern __shared__ __attribute__((aligned(16))) unsigned char paste_smem[];
+  const int S = p.M + 2;
+  float* pm = reinterpret_cast<float*>(paste_smem);
+  int* tab_i = reinterpret_cast<int*>(pm + S * S);
+  float* tab_f = reinterpret_cast<float*>(tab_i + kMaxTab);
   __shared__ long long red[kPasteThreads / 64];
   const int d = blockIdx.x / kPasteSplit, band = blockIdx.x % kPasteSplit, b = blockIdx.y, tid = threadIdx.x;
   const int nd = min(p.det_count[b], p.max_out);
+  const bool publisher = d == 0 && band == 0;               // also writes the image's total byte count
+  if (d >= nd && !publisher) return;
   const int im_h = (int)p.im_size[b * 2 + 0], im_w = (int)p.im_size[b * 2 + 1];
+  const float* det = p.dets + ((size_t)b * p.max_out + d) * 6;
+  int eb[4] = {0, 0, 0, 0}, r[4] = {0, 0, 0, 0};
+  int nbands = 1;
+  if (d < nd) {
+    expand_box_int(det, p.M, eb);
+    paste_rect(eb, im_h, im_w, r);
+    const long long a = (long long)(r[2] - r[0]) * (r[3] - r[1]);
+    nbands = (int)min((long long)kPasteSplit, max(1ll, (a + kBandPixels - 1) / kBandPixels));
+    if (band >= nbands) return;
+  }
   // byte offset = sum of the paste-rect areas of the detections before this one (block 0 also publishes the total)
   const int upto = (d == 0) ? nd : min(d, nd);
   long long acc = 0;
   for (int q = tid; q < upto; q += kPasteThreads) {
-    int eb[4], r[4];
-    expand_box_int(p.dets + ((size_t)b * p.max_out + q) * 6, p.M, eb);
-    paste_rect(eb, im_h, im_w, r);
-    acc += (long long)(r[2] - r[0]) * (r[3] - r[1]);
+    int qb[4], qr[4];
+    expand_box_int(p.dets + ((size_t)b * p.max_out + q) * 6, p.M, qb);
+    paste_rect(qb, im_h, im_w, qr);
+    acc += (long long)(qr[2] - qr[0]) * (qr[3] - qr[1]);
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((tid & 63) == 0) red[tid >> 6] = acc;
   __syncthreads();
   long long sum = 0;
   for (int q = 0; q < kPasteThreads / 64; q++) sum += red[q];
-  if (d == 0 && band == 0 && tid == 0) p.mask_bytes[b] = sum;
+  if (publisher && tid == 0) p.mask_bytes[b] = sum;
   if (d >= nd) return;
   const long long offset = (d == 0) ? 0 : sum;
 
-  const float* det = p.dets + ((size_t)b * p.max_out + d) * 6;
-  int eb[4], r[4];
-  expand_box_int(det, p.M, eb);
-  paste_rect(eb, im_h, im_w, r);
   int w = eb[2] - eb[0] + 1, h = eb[3] - eb[1] + 1;      // :197-198
   w = max(w, 1); h = max(h, 1);                          // :199-200
   if (band == 0 && tid < 4) {
@@ -102,7 +116,6 @@ __global__ __launch_bounds__(kPasteThreads) void mask_paste_kernel(PasteParams p
   if (band == 0 && tid == 0) p.mask_offsets[(size_t)b * p.max_out + d] = offset;
 
   // stage the zero-padded (M+2)x(M+2) mask of the detection's class (:185-195)
-  const int S = p.M + 2;
   const int cls = p.cls_specific ? (int)det[5] : 0;
   const size_t row = p.mask_index ? (size_t)p.mask_index[(size_t)b * p.max_out + d] : (size_t)b * p.max_out + d;
   const float* src = p.masks + (row * p.n_cls + cls) * p.M * p.M;
@@ -133,7 +146,7 @@ __global__ __launch_bounds__(kPasteThreads) void mask_paste_kernel(PasteParams p
   }
   // this workgroup's band of rows; 32-bit index math (area <= im_h * im_w < 2^31; a 64-bit division per pixel dominated
   // this loop before)
-  const int row0 = (int)((long long)rh * band / kPasteSplit), row1 = (int)((long long)rh * (band + 1) / kPasteSplit);
+  const int row0 = (int)((long long)rh * band / nbands), row1 = (int)((long long)rh * (band + 1) / nbands);
   for (int i = row0 * rw + tid; i < row1 * rw; i += kPasteThreads) {
     const int py = i / rw, px = i - py * rw;
     int sx, sx1, sy, sy1; float fx, fy;
@@ -167,7 +180,8 @@ DTC_API int dtc_mask_paste(const float* masks, const int32_t* mask_index, int n_
   p.n_cls = n_cls; p.M = M; p.max_out = max_out; p.cls_specific = cls_specific_mask; p.thresh = thresh_binarize;
   p.crops = crops; p.per_image_capacity = per_image_capacity; p.mask_boxes = mask_boxes; p.mask_rects = mask_rects;
   p.mask_offsets = mask_offsets; p.mask_bytes = mask_bytes;
-  hipLaunchKernelGGL(dtc::mask_paste_kernel, dim3(max_out * dtc::kPasteSplit, batch), dim3(dtc::kPasteThreads), 0,
+  const size_t lds = (size_t)(M + 2) * (M + 2) * sizeof(float) + (size_t)dtc::kMaxTab * (sizeof(int) + sizeof(float));
+  hipLaunchKernelGGL(dtc::mask_paste_kernel, dim3(max_out * dtc::kPasteSplit, batch), dim3(dtc::kPasteThreads), lds,
                      reinterpret_cast<hipStream_t>(stream), p);
   DTC_CHECK_LAUNCH();
   return DTC_OK;

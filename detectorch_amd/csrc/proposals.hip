@@ -24,6 +24,7 @@
 #include "radix_select.h"
 
 namespace dtc {
+DTC_PT_TABLE(proposals)
 
 constexpr int kRpnMaxLevels = 8;
 constexpr int kRpnMaxAnchors = 16;
@@ -128,22 +129,40 @@ __global__ __launch_bounds__(kHistThreads) void rpn_hist_kernel(RpnParams p) {
   if (L.K >= L.N) return;  // take everything: no selection needed
   const int seg = b * p.n_levels + l;
   const int chunk = blockIdx.x - L.chunk_begin;
+  [[maybe_unused]] const int ptb = blockIdx.y * gridDim.x + blockIdx.x;
+  DTC_PT(PASS, ptb, 0);
+  // the chunk's 16 scores per thread are requested FIRST (independent loads, back to back) and consumed after the histogram
+  // is cleared and the previous pass' digit is known: the load latency hides behind that work.  (A load -> LDS atomic loop
+  // paid one L2 round trip per element: 7.4 of the kernel's 9.2 us.)
+  const float* sc = L.cls + (size_t)b * L.N;
+  const int begin = chunk * kChunk, end = min(begin + kChunk, L.N);
+  float v[kChunk / kHistThreads];
+#pragma unroll
+  for (int u = 0; u < kChunk / kHistThreads; u++) {
+    const int i = begin + u * kHistThreads + (int)threadIdx.x;
+    v[u] = i < end ? sc[i] : 0.f;
+  }
   for (int i = threadIdx.x; i < kHistBins; i += kHistThreads) h[i] = 0;
   const SelState st = load_state<PASS>(p, seg, (uint32_t)L.K, sh);  // ends with a barrier (or needs one for PASS 0)
   if (PASS == 0) __syncthreads();
-  const float* sc = L.cls + (size_t)b * L.N;
-  const int begin = chunk * kChunk, end = min(begin + kChunk, L.N);
-  for (int i = begin + threadIdx.x; i < end; i += kHistThreads) {
-    const uint32_t o = float_to_ordered(sc[i]);
-    if (PASS == 0) atomicAdd(&h[o >> 20], 1u);
-    if (PASS == 1) { if ((o >> 20) == st.p0) atomicAdd(&h[(o >> 8) & 4095u], 1u); }
+  DTC_PT(PASS, ptb, 1);
+#pragma unroll
+  for (int u = 0; u < kChunk / kHistThreads; u++) {
+    const int i = begin + u * kHistThreads + (int)threadIdx.x;
+    if (i < end) {
+      const uint32_t o = float_to_ordered(v[u]);
+      if (PASS == 0) atomicAdd(&h[o >> 20], 1u);
+      if (PASS == 1) { if ((o >> 20) == st.p0) atomicAdd(&h[(o >> 8) & 4095u], 1u); }
+    }
   }
   __syncthreads();
+  DTC_PT(PASS, ptb, 2);
   uint32_t* G = p.hist + ((size_t)seg * 2 + PASS) * kHistBins;
   for (int i = threadIdx.x; i < kHistBins; i += kHistThreads) {
     const uint32_t v = h[i];
     if (v) atomicAdd(&G[i], v);
   }
+  DTC_PT(PASS, ptb, 3);
 }
 
 __global__ __launch_bounds__(kHistThreads) void rpn_compact_kernel(RpnParams p) {
@@ -160,6 +179,16 @@ __global__ __launch_bounds__(kHistThreads) void rpn_compact_kernel(RpnParams p) 
   const int seg = b * p.n_levels + l;
   const int chunk = blockIdx.x - L.chunk_begin;
   const bool take_all = L.K >= L.N;
+  [[maybe_unused]] const int ptb = blockIdx.y * gridDim.x + blockIdx.x;
+  DTC_PT(2, ptb, 0);
+  const float* sc = L.cls + (size_t)b * L.N;      // the chunk's scores: requested first, consumed behind the threshold look-up
+  const int begin = chunk * kChunk, end = min(begin + kChunk, L.N);
+  float v[kChunk / kHistThreads];
+#pragma unroll
+  for (int u = 0; u < kChunk / kHistThreads; u++) {
+    const int i = begin + u * kHistThreads + (int)threadIdx.x;
+    v[u] = i < end ? sc[i] : 0.f;
+  }
   if (threadIdx.x < 2) lcnt[threadIdx.x] = 0;
   KeyBand kb; kb.lo = kb.hi = 0;
   if (!take_all) {
@@ -168,11 +197,13 @@ __global__ __launch_bounds__(kHistThreads) void rpn_compact_kernel(RpnParams p) 
     kb = candidate_band(bl, bl | 0xffu, L.logit != 0, sh);
   }
   __syncthreads();
-  const float* sc = L.cls + (size_t)b * L.N;
-  const int begin = chunk * kChunk, end = min(begin + kChunk, L.N);
+  DTC_PT(2, ptb, 1);
   const int HW = L.H * L.W;
-  for (int i = begin + threadIdx.x; i < end; i += kHistThreads) {
-    const float s = sc[i];
+#pragma unroll
+  for (int u = 0; u < kChunk / kHistThreads; u++) {
+    const int i = begin + u * kHistThreads + (int)threadIdx.x;
+    if (i >= end) continue;
+    const float s = v[u];
     const uint32_t o = float_to_ordered(s);
     const bool is_gt = take_all || o > kb.hi;
     const bool is_cand = !take_all && o >= kb.lo && o <= kb.hi;
@@ -186,6 +217,7 @@ __global__ __launch_bounds__(kHistThreads) void rpn_compact_kernel(RpnParams p) 
     }
   }
   __syncthreads();
+  DTC_PT(2, ptb, 2);
   uint32_t* cnt = p.counters + (size_t)seg * 2;
   if (threadIdx.x < 2) gbase[threadIdx.x] = lcnt[threadIdx.x] ? atomicAdd(&cnt[threadIdx.x], lcnt[threadIdx.x]) : 0u;
   __syncthreads();
@@ -194,6 +226,7 @@ __global__ __launch_bounds__(kHistThreads) void rpn_compact_kernel(RpnParams p) 
   for (uint32_t j = threadIdx.x; j < lcnt[0]; j += kHistThreads)
     if (gbase[0] + j < (uint32_t)p.k_stride) gt[gbase[0] + j] = stage[j];
   for (uint32_t j = threadIdx.x; j < lcnt[1]; j += kHistThreads) cand[gbase[1] + j] = stage[kChunk - 1 - j];
+  DTC_PT(2, ptb, 3);
 }
 
 // generate_proposals.py:165-214 (weights (1,1,1,1)) + :216-238 + :151-163
@@ -229,13 +262,14 @@ __global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_decode_kernel(Rpn
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
   __shared__ uint32_t sh[2];
-  __shared__ uint32_t hsel[2048];
+  __shared__ __attribute__((aligned(16))) uint32_t hsel[2048];
   __shared__ int wave_tot[kSortDecodeThreads / 64];
   __shared__ int running;
   const int seg = blockIdx.x;
   const int b = seg / p.n_levels, l = seg - b * p.n_levels;
   const RpnLevelDev& L = p.lv[l];
   const int tid = threadIdx.x;
+  DTC_PT(3, seg, 0);
   const uint32_t n_gt = min(p.counters[(size_t)seg * 2], (uint32_t)p.k_stride);
   const uint32_t n_cand = p.counters[(size_t)seg * 2 + 1];
   const uint64_t* gt = p.gt_keys + (size_t)seg * p.k_stride;
@@ -290,7 +324,9 @@ __global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_decode_kernel(Rpn
     }
   }
   __syncthreads();
+  DTC_PT(3, seg, 1);
   block_bitonic_sort<kSortDecodeThreads>(keys, np2);
+  DTC_PT(3, seg, 2);
 
   // ranks [0, K) in score order: decode, clip, filter, ordered compaction
   const float* sc = L.cls + (size_t)b * L.N;
@@ -340,6 +376,7 @@ __global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_decode_kernel(Rpn
     __syncthreads();
   }
   if (tid == 0) p.out_counts[seg] = running;
+  DTC_PT(3, seg, 3);
 }
 
 // After NMS: gather the kept proposals of every segment.  keep [S, keep_stride] positions into the sorted boxes.

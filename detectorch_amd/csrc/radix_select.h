@@ -5,37 +5,54 @@
 
 namespace dtc {
 
-// Wave 0 of the block: find the digit d with  sum(h[d+1..]) < k <= sum(h[d..])  and the remaining rank inside it.
-// Result broadcast through sh[0..1].  nbins <= 4096, a multiple of 64.
+// Find the digit d with  sum(h[d+1..]) < k <= sum(h[d..])  and the remaining rank inside it; result broadcast through
+// sh[0..1].  Every thread of the block calls (blockDim >= 256); nbins is a multiple of 256, <= 4096; h (global or LDS) is
+// 16-byte aligned.  The first 256 threads own nbins / 256 consecutive bins each (vector loads), sum them, suffix-scan the sums
+// with wave shuffles + one LDS hand-over of the four wave totals, and the one thread whose range holds the k-th element walks
+// its <= 16 bins.  (Rounds 1-2 had wave 0 alone read 64 bins per lane with a stride of 64 -- 64 uncoalesced loads per lane from
+// the global histogram, 32-way bank conflicts on an LDS one -- and walk them serially: 3.3-4.4 us per call on the global
+// histogram, paid by every workgroup of rpn_hist<1> once and of rpn_compact twice.)
 __device__ __forceinline__ void select_digit(const uint32_t* __restrict__ h, int nbins, uint32_t k, uint32_t* sh) {
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    const int per = nbins / 64;
-    uint32_t local[64];
-    uint32_t tot = 0;
+  __shared__ uint32_t sd_wtot[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int per = nbins >> 8;
+  uint32_t loc[16];
+  uint32_t part = 0, suf = 0;
+  if (t < 256) {
+    if ((per & 3) == 0) {
+      const uint4* h4 = reinterpret_cast<const uint4*>(h + t * per);
 #pragma unroll
-    for (int i = 0; i < 64; i++) {
-      local[i] = i < per ? h[lane * per + i] : 0u;
-      tot += local[i];
+      for (int i = 0; i < 4; i++) {
+        const uint4 q = i < (per >> 2) ? h4[i] : make_uint4(0u, 0u, 0u, 0u);
+        loc[4 * i] = q.x; loc[4 * i + 1] = q.y; loc[4 * i + 2] = q.z; loc[4 * i + 3] = q.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; i++) loc[i] = i < per ? h[t * per + i] : 0u;
     }
-    // inclusive suffix sum over lanes: suf = sum of tot for lanes >= lane
-    uint32_t suf = tot;
+#pragma unroll
+    for (int i = 0; i < 16; i++) part += loc[i];
+    suf = part;                                   // inclusive suffix sum over the lanes of this wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t o = __shfl_down(suf, off, 64);
       if (lane + off < 64) suf += o;
     }
-    const uint32_t above = suf - tot;  // elements in bins owned by higher lanes
-    if (above < k && k <= suf) {
-      uint32_t acc = above;
+    if (lane == 0) sd_wtot[wv] = suf;
+  }
+  __syncthreads();
+  if (t < 256) {
+    uint32_t above = suf - part;                  // elements in bins owned by higher threads
+    for (int q = wv + 1; q < 4; q++) above += sd_wtot[q];
+    if (above < k && k <= above + part) {
+      uint32_t acc = above, rem = 0;
       int d = 0;
-      uint32_t rem = 0;
       bool found = false;
 #pragma unroll
-      for (int i = 63; i >= 0; i--) {
+      for (int i = 15; i >= 0; i--) {
         if (i < per && !found) {
-          if (acc + local[i] >= k) { d = lane * per + i; rem = k - acc; found = true; }
-          acc += local[i];
+          if (acc + loc[i] >= k) { d = t * per + i; rem = k - acc; found = true; }
+          acc += loc[i];
         }
       }
       sh[0] = (uint32_t)d;
