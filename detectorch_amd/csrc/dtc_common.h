@@ -9,6 +9,8 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/detectorch_hip.h"
 
 #define DTC_WAVE 64
@@ -18,6 +20,19 @@
   do {                                                     \
     hipError_t e__ = hipGetLastError();                    \
     if (e__ != hipSuccess) return DTC_ELAUNCH;             \
+  } while (0)
+
+// Raise a (non-template) kernel's dynamic-LDS limit once per process; thread-safe (std::call_once), the status of the one
+// hipFuncSetAttribute call is remembered, so every caller of a failed raise gets DTC_ELAUNCH.
+#define DTC_RAISE_LDS_ONCE(kernel, bytes)                                                                            \
+  do {                                                                                                               \
+    static std::once_flag once__;                                                                                    \
+    static hipError_t rc__ = hipSuccess;                                                                             \
+    std::call_once(once__, [] {                                                                                      \
+      rc__ = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                 (bytes));                                                                           \
+    });                                                                                                              \
+    if (rc__ != hipSuccess) return DTC_ELAUNCH;                                                                      \
   } while (0)
 
 namespace dtc {

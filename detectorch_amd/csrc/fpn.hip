@@ -457,11 +457,7 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
   if (roi_order) { const size_t so = (size_t)(dtc::next_pow2(post_nms_top_n) < 4 ? 4 : dtc::next_pow2(post_nms_top_n)) * sizeof(uint64_t) * 2; if (so > smem) smem = so; }
   if (post_nms_top_n > 16384) return DTC_EUNSUPPORTED;
   if (smem > 32 * 1024) {   // static __shared__ of the kernel comes on top: raise the limit well before dynamic + static reaches 64 KB
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::fpn_collect_distribute_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess) return DTC_ELAUNCH;
-      raised = true;
-    }
+    DTC_RAISE_LDS_ONCE(dtc::fpn_collect_distribute_kernel, 144 * 1024);
   }
   static const bool no_fast = getenv("DTC_FPN_NO_FAST") != nullptr;     // A/B knob (general kernel), resolved once
   const bool fast = post_nms_top_n <= dtc::kFastMaxTop && in_stride <= 1024 && n_max <= 8192 &&

@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "block_sort.h"
 #include "dtc_common.h"
 
@@ -58,6 +60,12 @@ __global__ __launch_bounds__(kSortThreads) void segment_sort_desc_kernel(
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float box_area(float4 b) { return (b.z - b.x + 1.f) * (b.w - b.y + 1.f); }  // cython_nms.pyx:44
 
+// v_max_f32 / v_min_f32 on operands that come straight from memory.  fmaxf() makes the compiler canonicalise such operands
+// first (v_max x, x, x: signalling NaNs), one extra instruction per LDS-broadcast row coordinate and pair; the hardware
+// instruction in IEEE mode already quiets them, and for everything that is not a signalling NaN the result is the same.
+__device__ __forceinline__ float vmax(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float vmin(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+
 constexpr int kMaskWaves = 4;  // a workgroup = 4 wavefronts = 4 consecutive column blocks of one row block
 
 __global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4* __restrict__ boxes,
@@ -84,9 +92,11 @@ __global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4*
     __syncthreads();                                          // previous tile's readers are done with rbox_s
     if (wv == 0) {
       const int row = rb * 64 + lane;
+      // padding rows: a box that intersects nothing (inter = 0 against any column) with a stand-in area of 1, so that
+      // u = 1 + areas[j] stays positive and the row loop's fast path holds for them too (their words are never stored)
       const float4 rbx = row < n ? B[row] : make_float4(0.f, 0.f, -1.f, -1.f);
       rbox_s[lane] = rbx;
-      rarea_s[lane] = box_area(rbx);
+      rarea_s[lane] = row < n ? box_area(rbx) : 1.f;
     }
     __syncthreads();
     const int cb = cb0 + wv;
@@ -95,30 +105,67 @@ __global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4*
     const bool col_ok = col < n;
     const float4 cbox = col_ok ? B[col] : make_float4(0.f, 0.f, -1.f, -1.f);
     const float carea = box_area(cbox);
+    // Two instances of the row loop, chosen per wavefront (cb, rb are wave-uniform): only the DIAGONAL tile needs the
+    // (_j > _i) test of cython_nms.pyx:72 -- above the diagonal every column index exceeds every row index -- and only it
+    // produces the transposed word the reduce kernel resolves the in-block chain on.  The kernel is VALU-bound (30 instructions
+    // per pair in round 1), so the loop is written for instruction count: see the notes at vmax and inside.
     uint64_t myword = 0, mycol = 0;
-#pragma unroll 8
-    for (int i = 0; i < 64; i++) {
-      const float4 r = rbox_s[i];                                // uniform address: LDS broadcast
-      const float iarea = rarea_s[i];
-      const float xx1 = fmaxf(r.x, cbox.x), yy1 = fmaxf(r.y, cbox.y);          // cython_nms.pyx:76-77
-      const float xx2 = fminf(r.z, cbox.z), yy2 = fminf(r.w, cbox.w);          // :78-79
-      const float w = fmaxf(0.0f, xx2 - xx1 + 1.f), h = fmaxf(0.0f, yy2 - yy1 + 1.f);  // :80-81
-      const float inter = w * h;                                               // :82
-      // :83-84  `inter / (iarea + areas[j] - inter) >= thresh` with an IEEE float division.  The division is only needed
-      // when inter is within 2^-21 (relative) of thresh * u: outside that band the outcome of the rounded quotient is
-      // already decided (the float products below carry <= 3 * 2^-24 relative error), so almost every pair costs three
-      // multiplies and two compares instead of the ~15-instruction division sequence.  u <= 0 (degenerate boxes) always
-      // takes the division, exactly like the reference.
-      const float u = iarea + carea - inter;
-      const float pu = thresh * u;
-      bool ge = inter >= pu * 1.00000048f;                 // 1 + 2^-21: certainly >= thresh
-      const bool lt = inter <= pu * 0.99999952f;           // 1 - 2^-21: certainly <  thresh
-      if (!(u > 0.f) || !(thresh > 0.f) || (!ge && !lt)) ge = fdiv(inter, u) >= thresh;
-      const bool sup = col_ok && (col > rb * 64 + i) && ge;                    // :72 (_j > _i), :84
-      const uint64_t word = __ballot(sup);
-      if (lane == i) myword = word;
-      mycol |= (uint64_t)(sup ? 1 : 0) << i;             // column view of the same tile: rows that suppress MY column
-    }
+    // LDS row tables behind a base the optimiser must keep in a VGPR: with a uniform (SGPR) base every ds_read of the unrolled
+    // loop was preceded by a v_mov of its address
+    int lds_base = 0;
+    asm volatile("" : "+v"(lds_base));
+    const float4* rb_v = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(rbox_s) + lds_base);
+    const float* ra_v = reinterpret_cast<const float*>(reinterpret_cast<const char*>(rarea_s) + lds_base);
+    const int nrow = min(64, n - rb * 64);                    // rows past the segment's count are never stored: not computed
+    const bool thr_pos = thresh > 0.f;
+    auto rows = [&](auto diag_tag) {
+      constexpr bool kDiag = decltype(diag_tag)::value;
+      // chunks of 8 rows, the chunk unrolled by hand (a run-time trip count keeps the compiler from unrolling, and the loop
+      // overhead is a quarter of the body); rows of the last chunk past nrow are padding rows: computed, never stored
+      for (int i0 = 0; i0 < nrow; i0 += 8) {
+        uint32_t cbits = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+        const int i = i0 + k;
+        const float4 r = rb_v[i];                                  // uniform address: LDS broadcast
+        const float iarea = ra_v[i];
+        const float xx1 = vmax(r.x, cbox.x), yy1 = vmax(r.y, cbox.y);            // cython_nms.pyx:76-77
+        const float xx2 = vmin(r.z, cbox.z), yy2 = vmin(r.w, cbox.w);            // :78-79
+        const float w = fmaxf(0.0f, xx2 - xx1 + 1.f), h = fmaxf(0.0f, yy2 - yy1 + 1.f);  // :80-81
+        const float inter = w * h;                                               // :82
+        // :83-84  `inter / (iarea + areas[j] - inter) >= thresh` with an IEEE float division.  Rounding is monotone, so the
+        // rounded quotient is >= thresh whenever the exact one is, and < thresh whenever the exact one is below
+        // thresh * (1 - 2^-24): the division itself is needed only if inter - thresh * u cannot be signed reliably.
+        // d = fl(inter - fl(thresh * u)) carries <= 2^-23 * pu of error, so outside the band |d| <= 2^-21 * pu its sign IS the
+        // answer: five instructions and ONE compare per pair, and that compare is the ballot mask itself.  (The previous form
+        // -- two scaled products, three compares -- made the compiler rebuild the mask with a 0/1 select + re-compare.)
+        // u <= 0 (degenerate boxes), thresh <= 0 and the band take the division, exactly like the reference; they are decided
+        // per wavefront (a uniform branch: about one pair in 10^6 is that close to the threshold).
+        const float u = iarea + carea - inter;
+        const float pu = thresh * u;
+        const float d = inter - pu;
+        const float t = __builtin_fabsf(d) - pu * 4.76837158203125e-07f;         // 2^-21 (exact scaling)
+        const float m = vmin(t, u);                          // <= 0 (or NaN-free t with u NaN: not suppressed either way)
+        uint64_t word;
+        bool sup;
+        if (__builtin_amdgcn_ballot_w64(!(m > 0.f)) == 0ull && thr_pos) {
+          // padding columns need no test here: their box (0, 0, -1, -1) intersects nothing (inter = 0, u = iarea > 0 -> d < 0)
+          sup = kDiag ? (d > 0.f) && (lane > i) : (d > 0.f);                     // :72 (_j > _i) on the diagonal tile only
+          word = __builtin_amdgcn_ballot_w64(sup);
+        } else {
+          const bool need = !(m > 0.f) || !thr_pos;
+          const bool gd = fdiv(inter, u) >= thresh;
+          sup = col_ok && (need ? gd : d > 0.f);
+          if (kDiag) sup = sup && (lane > i);
+          word = __builtin_amdgcn_ballot_w64(sup);
+        }
+        if (lane == i) myword = word;
+        if (kDiag) cbits |= sup ? (1u << k) : 0u;          // column view of the same tile: rows that suppress MY column
+        }
+        if (kDiag) mycol |= (uint64_t)cbits << i0;
+      }
+    };
+    if (cb == rb) rows(std::true_type{}); else rows(std::false_type{});
     const int row = rb * 64 + lane;
     if (row < n) mask[((size_t)s * n_stride + row) * ncb_stride + cb] = myword;
     if (cb == rb && col_ok) diag_t[(size_t)s * n_stride + col] = mycol;   // transposed diagonal tile for the reduce
@@ -295,11 +342,7 @@ DTC_API int dtc_segment_sort_desc(const float* scores, int score_stride_elems, c
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t smem = (size_t)dtc::next_pow2(n_stride) * sizeof(uint64_t);
   if (smem > 32 * 1024) {   // static __shared__ of the kernel comes on top: raise the limit well before dynamic + static reaches 64 KB
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::segment_sort_desc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
-      raised = true;
-    }
+    DTC_RAISE_LDS_ONCE(dtc::segment_sort_desc_kernel, 160 * 1024);
   }
   hipLaunchKernelGGL(dtc::segment_sort_desc_kernel, dim3(n_seg), dim3(dtc::kSortThreads), smem, s, scores,
                      score_stride_elems, boxes, box_stride_elems, counts, n_stride, order, sorted_boxes, sorted_scores);
@@ -336,11 +379,7 @@ DTC_API int dtc_nms(const float* dets, int n, float thresh, void* workspace, siz
   if (rc != DTC_OK) return rc;
   const size_t smem = (size_t)dtc::next_pow2(n) * sizeof(uint64_t);
   if (smem > 32 * 1024) {   // static __shared__ of the kernel comes on top: raise the limit well before dynamic + static reaches 64 KB
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::nms_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
-      raised = true;
-    }
+    DTC_RAISE_LDS_ONCE(dtc::nms_finalize_kernel, 160 * 1024);
   }
   hipLaunchKernelGGL(dtc::nms_finalize_kernel, dim3(1), dim3(dtc::kSortThreads), smem, s, keep, cnt, order, keep_out, keep_count);
   DTC_CHECK_LAUNCH();
@@ -465,11 +504,7 @@ DTC_API int dtc_soft_nms(const float* dets, int n, float sigma, float overlap_th
   if (n > 6000) return DTC_EUNSUPPORTED;
   if (!dets || !dets_out || !inds_out) return DTC_EINVAL;
   const size_t smem = (size_t)n * (6 * 4 + 1) + 16;
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::soft_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DTC_ELAUNCH;
-    raised = true;
-  }
+  DTC_RAISE_LDS_ONCE(dtc::soft_nms_kernel, 160 * 1024);
   hipLaunchKernelGGL(dtc::soft_nms_kernel, dim3(1), dim3(64), smem, s, dets, n, sigma, overlap_thresh, score_thresh, method,
                      dets_out, inds_out, n_out);
   DTC_CHECK_LAUNCH();

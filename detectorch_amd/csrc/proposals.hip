@@ -470,11 +470,7 @@ DTC_API int dtc_rpn_topk_decode(const dtc_rpn_level* levels, int n_levels, int b
   const int sort_cap = dtc::next_pow2(plan.k_stride) <= 1024 ? 2048 : dtc::next_pow2(plan.k_stride);
   const size_t smem = (size_t)sort_cap * sizeof(uint64_t);
   if (smem > 32 * 1024) {   // static __shared__ of the kernel comes on top: raise the limit well before dynamic + static reaches 64 KB
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::rpn_sort_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess) return DTC_ELAUNCH;
-      raised = true;
-    }
+    DTC_RAISE_LDS_ONCE(dtc::rpn_sort_decode_kernel, 144 * 1024);
   }
   hipLaunchKernelGGL(dtc::rpn_sort_decode_kernel, dim3(plan.n_seg), dim3(dtc::kSortDecodeThreads), smem, s, p, sort_cap);
   DTC_CHECK_LAUNCH();
