@@ -228,6 +228,53 @@ def test_mask_paste_vs_oracle_and_segm_results(hip, oracle):
     assert n_ones > 1000
 
 
+@pytest.mark.parametrize("M,max_out", [(28, 48), (14, 48), (28, 600)])
+def test_mask_paste_crops_all_box_sizes_vs_oracle(hip, oracle, M, max_out):
+    """Raw crops of dtc_mask_paste against the oracle for rectangles from 1 x 1 to the whole frame (one band ... the band cap,
+    down- and up-scaling, 64-column chunk edges), two images with different detection counts; max_out 600 takes the
+    no-helper path of the kernel (more detection slots than its LDS prefix tables hold)."""
+    rs = synth.rng(6, 11 + M + max_out)
+    im_h, im_w = 500, 833
+    counts = [40, 17]
+    boxes = []
+    for n in counts:
+        rb = synth.make_rois(rs, n, im_h=im_h, im_w=im_w, min_side=2, max_side=300)
+        rb[0] = [-40, -30, im_w + 30, im_h + 20]        # larger than the frame: every band, clipped on all sides
+        rb[1] = [10, 10, 10.2, 10.3]                    # 1 x 1 target
+        rb[2] = [100, 50, 100 + 63, 400]                # one column chunk, tall
+        rb[3] = [100, 50, 100 + 64, 60]                 # chunk edge + 1
+        rb[4] = [5, 5, 700, 9]                          # wide and flat: more source rows than target rows
+        rb[5] = [300, 100, 303, 480]                    # narrow and tall: the row table is exceeded at kMaxRowTab
+        boxes.append(rb)
+    B = len(counts)
+    dets = np.zeros((B, max_out, 6), np.float32)
+    cls = np.zeros((B, max_out), np.int64)
+    for b, rb in enumerate(boxes):
+        dets[b, :len(rb), :4] = rb
+        cls[b, :len(rb)] = rs.randint(1, 5, len(rb))
+        dets[b, :len(rb), 5] = cls[b, :len(rb)]
+        dets[b, :len(rb), 4] = 0.9
+    masks = synth.make_masks(rs, B * max_out, 5, M)
+    cap = im_h * im_w * 12
+    out = hip.mask_paste(cu(masks), cu(dets), cu(np.array(counts, np.int32)), cu(np.array([[im_h, im_w]] * B, np.float32)), M, cap)
+    crops = out["crops"].cpu().numpy()
+    offs, rects, nbytes = out["offsets"].cpu().numpy(), out["rects"].cpu().numpy(), out["bytes"].cpu().numpy()
+    for b, rb in enumerate(boxes):
+        pos = 0
+        for d in range(len(rb)):
+            box, crop = oracle.mask_resize_binarize(masks[b * max_out + d, cls[b, d]], rb[d])
+            x0, x1 = max(box[0], 0), min(box[2] + 1, im_w)
+            y0, y1 = max(box[1], 0), min(box[3] + 1, im_h)
+            assert list(rects[b, d]) == [x0, y0, max(x1, x0), max(y1, y0)]
+            assert offs[b, d] == pos
+            if x1 > x0 and y1 > y0:
+                ref = crop[y0 - box[1]:y1 - box[1], x0 - box[0]:x1 - box[0]]
+                got = crops[b, pos:pos + ref.size].reshape(ref.shape)
+                assert np.array_equal(got, ref), (b, d, ref.shape)
+                pos += ref.size
+        assert nbytes[b] == pos
+
+
 def test_zero_detections_everywhere(hip, oracle):
     """All class scores below the 0.05 threshold: empty results must flow through every stage (result_utils.py:126-168
     with no survivors; the eval loop `continue`s at eval_mask_FPN.ipynb:244)."""
