@@ -21,6 +21,8 @@
 
 namespace dtc {
 
+DTC_PT_TABLE(nms)
+
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. segment sort.  scores [S, n_stride] (+counts) -> order [S, n_stride] int32 (original index of the k-th best),
 //    optional gathered boxes [S, n_stride, 4] / scores.
@@ -274,6 +276,145 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const uint64_t* __restri
   if (lane == 0) keep_count[s] = kept;
 }
 
+// The same walk with the segment's whole suppression matrix in LDS: for few, long segments (the RPN call: 40 segments of 1000
+// boxes, 16 row blocks each).  The one-wave kernel above pays one L2 round trip per row block that its one-block prefetch
+// cannot hide, and ~700 instructions per block in a single wavefront (guarded 64-bit global addressing of 16 row words, register
+// ping-pong, shuffle merge): 1.5 us per block, 25 us for the RPN call.  Here 256 threads copy the matrix (n rows x ncb words,
+// + the transposed diagonal words) into LDS with all loads in flight, then wavefront 0 walks the blocks from LDS:
+//   * row words are read unguarded: rows past n and words left of the diagonal (never written by nms_mask) are zero in LDS;
+//   * lane (rg, cbl) ORs the words of the KEPT rows 4k + rg with a sign-extended bit field as the mask (3 instructions per
+//     row), the four row groups meet in LDS with one ds_or_b64;
+//   * no prefetch registers: the 17 LDS reads of a block are issued at the top of its iteration, under the resolve.
+constexpr int kReduceLdsThreads = 256;
+
+__global__ __launch_bounds__(kReduceLdsThreads) void nms_reduce_lds_kernel(const uint64_t* __restrict__ mask,
+                                                                           const uint64_t* __restrict__ diag_t,
+                                                                           const int32_t* __restrict__ counts, int n_stride,
+                                                                           int ncb_stride, int max_keep, int32_t* __restrict__ keep,
+                                                                           int keep_stride, int32_t* __restrict__ keep_count) {
+  __shared__ uint64_t removed[256];            // one bit per box
+  extern __shared__ __attribute__((aligned(16))) unsigned char reduce_smem[];   // [nrow_pad * ncb_stride] + [nrow_pad] words
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, rg = lane >> 4, cbl = lane & 15;
+  const int nrow_pad = ncb_stride * 64;        // LDS image: ncb_stride x 64 rows; rows past the segment's count are zero-filled
+  const uint64_t* Mg = mask + (size_t)s * n_stride * ncb_stride;
+  const uint64_t* DTg = diag_t + (size_t)s * n_stride;
+  int32_t* K = keep + (size_t)s * keep_stride;
+  const int cap = max_keep > 0 ? min(max_keep, keep_stride) : keep_stride;
+  uint64_t* Ml = reinterpret_cast<uint64_t*>(reduce_smem);
+  uint64_t* DTl = Ml + (size_t)nrow_pad * ncb_stride;
+  DTC_PT(0, s, 0);
+  removed[tid] = 0;
+  int n;
+  {
+    // 16-byte copies (ncb_stride is even and <= 16: the launcher checks) of the words on and right of the diagonal, every load
+    // of a thread in flight at once -- and issued BEFORE the segment's count is known (the count is one more dependent global
+    // round trip): rows of the workspace past the count hold stale words, they are replaced by zeros on the way into LDS, as
+    // are the words left of the diagonal (never written by nms_mask)
+    constexpr int kPerThread = 32;             // 32 x 256 x 16 B = 128 KB
+    const int ppr = ncb_stride >> 1;           // 16-byte pairs per row
+    const int npair = nrow_pad * ppr;
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(Mg);
+    ulonglong2* dst = reinterpret_cast<ulonglong2*>(Ml);
+    uint64_t dv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int i = tid + k * kReduceLdsThreads; dv[k] = i < n_stride ? DTg[i] : 0ull; }
+    ulonglong2 v[kPerThread];
+    // (row, pair) of element tid + k * 256, stepped without a division per element
+    const int row0 = tid / ppr, pr0 = tid - row0 * ppr, drow = kReduceLdsThreads / ppr, dpr = kReduceLdsThreads - drow * ppr;
+    int row = row0, pr = pr0;
+#pragma unroll
+    for (int k = 0; k < kPerThread; k++) {
+      const int i = tid + k * kReduceLdsThreads;
+      v[k] = make_ulonglong2(0, 0);
+      if (i < npair && row < n_stride && 2 * pr + 1 >= (row >> 6)) v[k] = src[i];
+      row += drow; pr += dpr;
+      if (pr >= ppr) { pr -= ppr; row++; }
+    }
+    n = counts ? min(counts[s], n_stride) : n_stride;
+    row = row0; pr = pr0;
+#pragma unroll
+    for (int k = 0; k < kPerThread; k++) {
+      const int i = tid + k * kReduceLdsThreads;
+      if (i < npair) dst[i] = row < n ? v[k] : make_ulonglong2(0, 0);
+      row += drow; pr += dpr;
+      if (pr >= ppr) { pr -= ppr; row++; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int i = tid + k * kReduceLdsThreads; if (i < nrow_pad) DTl[i] = i < n ? dv[k] : 0ull; }
+  }
+  const int ncb = (n + 63) >> 6;
+  __syncthreads();
+  DTC_PT(0, s, 1);
+  if (tid >= 64) return;                       // the serial part belongs to wavefront 0: no workgroup barrier below
+  int kept = 0;
+  // byte address of this lane's word of row rg in LDS; row block rb, row 4k + rg, column chunk cbase: + the offsets below
+  const uint32_t row_bytes = (uint32_t)ncb_stride * 8u;
+  const char* lane_base = reinterpret_cast<const char*>(Ml) + (uint32_t)rg * row_bytes + (uint32_t)cbl * 8u;
+  for (int rb = 0; rb < ncb && kept < cap; rb++) {
+    const uint64_t diag = DTl[rb * 64 + lane];
+    // the 16 row words of this block (rows 4k + rg, column word cbl of the chunk that holds the diagonal) are read now, under
+    // the resolve: they do not depend on it
+    const char* blk = lane_base + (uint32_t)rb * 64u * row_bytes;
+    uint64_t w[16];
+    {
+      const char* src = blk + (uint32_t)(rb & ~15) * 8u;
+#pragma unroll
+      for (int k = 0; k < 16; k++) w[k] = *reinterpret_cast<const uint64_t*>(src + (uint32_t)(4 * k) * row_bytes);
+    }
+    const int left = n - rb * 64;
+    const uint64_t valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+    uint64_t cand = valid & ~removed[rb];
+    cand = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cand >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cand);   // uniform by construction: keep it in SGPRs
+    // in-block greedy resolve as a fixed point (see nms_reduce_kernel)
+    uint64_t keepw = cand;
+    if (cand != 0) {
+      for (int it = 0; it < 64; it++) {
+        const bool k_i = ((cand >> lane) & 1ull) && ((diag & keepw) == 0ull);
+        const uint64_t nk = __ballot(k_i);
+        if (nk == keepw) break;
+        keepw = nk;
+      }
+      const int room = cap - kept;               // keep[:max_keep]: only the first `room` survivors of this block count
+      if (__builtin_popcountll(keepw) > room) {
+        uint64_t t = keepw, kk = 0;
+        for (int q = 0; q < room; q++) { kk |= t & (~t + 1ull); t &= t - 1ull; }
+        keepw = kk;
+      }
+      kept += __builtin_popcountll(keepw);
+    }
+    if (rb + 1 < ncb && kept < cap && keepw != 0ull) {
+      // bit 4k of (keepw >> rg) says whether row 4k + rg is kept
+      const uint64_t km = keepw >> rg;
+      const uint32_t km_lo = (uint32_t)km, km_hi = (uint32_t)(km >> 32);
+      for (int cbase = rb & ~15; cbase < ncb; cbase += 16) {
+        if (cbase != (rb & ~15)) {
+          const char* src = blk + (uint32_t)cbase * 8u;
+#pragma unroll
+          for (int k = 0; k < 16; k++) w[k] = *reinterpret_cast<const uint64_t*>(src + (uint32_t)(4 * k) * row_bytes);
+        }
+        uint32_t acc_lo = 0, acc_hi = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int m = k < 8 ? __builtin_amdgcn_sbfe((int)km_lo, 4 * k, 1) : __builtin_amdgcn_sbfe((int)km_hi, 4 * (k - 8), 1);   // 0 / -1
+          acc_lo |= (uint32_t)w[k] & (uint32_t)m;
+          acc_hi |= (uint32_t)(w[k] >> 32) & (uint32_t)m;
+        }
+        const uint64_t acc = ((uint64_t)acc_hi << 32) | acc_lo;
+        if (acc != 0ull && cbase + cbl < ncb) atomicOr(reinterpret_cast<unsigned long long*>(&removed[cbase + cbl]), (unsigned long long)acc);
+      }
+    }
+    if ((keepw >> lane) & 1ull) {               // off the chain: the kept positions of this block leave after the OR is issued
+      const int before = __builtin_popcountll(keepw & ((1ull << lane) - 1ull));
+      K[kept - __builtin_popcountll(keepw) + before] = rb * 64 + lane;
+    }
+    // LDS operations of one wavefront retire in order; the compiler must not carry `removed` across in registers
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if (lane == 0) keep_count[s] = kept;
+  DTC_PT(0, s, 2);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // finalize for the single-segment drop-in: kept positions (score order) -> ascending ORIGINAL indices, int64.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -327,8 +468,16 @@ DTC_API int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg,
   hipLaunchKernelGGL(dtc::nms_mask_kernel, dim3(gx, 1, n_seg), dim3(64 * dtc::kMaskWaves), 0, s,
                      reinterpret_cast<const float4*>(boxes), counts, n_stride, ncb, thresh, mask, diag_t);
   DTC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dtc::nms_reduce_kernel, dim3(n_seg), dim3(64), 0, s, mask, diag_t, counts, n_stride, ncb, max_keep, keep,
-                     keep_stride, keep_count);
+  // few long segments whose matrix fits LDS (the RPN call): the LDS walk (see the kernel); else the one-wave walk
+  const size_t lds_need = ((size_t)ncb * 64 * ncb + (size_t)ncb * 64) * sizeof(uint64_t);
+  if (n_seg <= 512 && ncb >= 4 && ncb <= 16 && (ncb & 1) == 0 && lds_need <= 150 * 1024) {
+    if (lds_need > 48 * 1024) DTC_RAISE_LDS_ONCE(dtc::nms_reduce_lds_kernel, 152 * 1024);   // + 2 KB static
+    hipLaunchKernelGGL(dtc::nms_reduce_lds_kernel, dim3(n_seg), dim3(dtc::kReduceLdsThreads), lds_need, s, mask, diag_t, counts,
+                       n_stride, ncb, max_keep, keep, keep_stride, keep_count);
+  } else {
+    hipLaunchKernelGGL(dtc::nms_reduce_kernel, dim3(n_seg), dim3(64), 0, s, mask, diag_t, counts, n_stride, ncb, max_keep, keep,
+                       keep_stride, keep_count);
+  }
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }

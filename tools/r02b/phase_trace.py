@@ -17,7 +17,8 @@ L = hip.lib()
 K, B, M = 4, 64, 24
 tables = {"proposals": ["rpn_hist<0>", "rpn_hist<1>", "rpn_compact", "rpn_sort_decode"],
           "detections": ["det_candidates", "det_finalize", None, None], "fpn": ["fpn_fast(box)", "fpn_fast(mask)", None, None],
-          "mask_paste": ["paste(main)", "paste(helper)", None, None]}
+          "mask_paste": ["paste(main)", "paste(helper)", None, None],
+          "nms": ["nms_reduce(lds)", "nms_reduce(1 wave)", None, None]}
 for name, kernels in tables.items():
     fn = getattr(L, "dtc_debug_phase_trace_" + name)
     fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
