@@ -171,6 +171,20 @@ struct FinParams {
   int32_t* det_count;         // [B]
 };
 
+// off[c] = sum of cnt(c') for c' < c, c = 0 .. nseg (off[nseg] = total); one wavefront, nseg <= 256.
+template <typename F> __device__ __forceinline__ void fin_prefix(int* off, F cnt, int nseg, int lane) {
+  int v[4], t = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { v[k] = cnt(lane * 4 + k); t += v[k]; }
+  int incl = t;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+  int e = incl - t;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int c = lane * 4 + k; if (c <= nseg) off[c] = e; e += v[k]; }
+  if (lane == 63 && nseg >= 256) off[nseg] = e;
+}
+
 constexpr int kFinStage = 6144;   // kept entries staged in LDS (ordered score + class/candidate id); more -> global path
 
 __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) {
@@ -186,13 +200,9 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
   const int nseg = p.n_cls - 1;
   const int seg0 = b * nseg;
   DTC_PT(1, b, 0);
-  if (tid < nseg) ccnt[tid] = p.keep_count[seg0 + tid];
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int c = 0; c < nseg; c++) { koff[c] = acc; acc += ccnt[c]; }
-    koff[nseg] = acc;
-  }
+  // exclusive prefix of the per-class kept counts: wavefront 0, four classes per lane (nseg <= kFinMaxCls = 256), shuffle scan
+  // -- a serial loop of thread 0 over 80 LDS words was 2 us of this kernel's 10 us prologue
+  if (wv == 0) fin_prefix(koff, [&](int c) { return c < nseg ? p.keep_count[seg0 + c] : 0; }, nseg, lane);
   __syncthreads();
   const int total = koff[nseg];
   const bool staged = total <= kFinStage;
@@ -260,11 +270,9 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
   }
   __syncthreads();
   DTC_PT(1, b, 3);
-  if (tid == 0) {
-    int acc = 0;
-    for (int c = 0; c < nseg; c++) { coff[c] = acc; acc += ccnt[c]; }
-    coff[nseg] = acc;
-    p.det_count[b] = acc;
+  if (wv == 0) {
+    fin_prefix(coff, [&](int c) { return c < nseg ? ccnt[c] : 0; }, nseg, lane);
+    if (lane == 0) p.det_count[b] = coff[nseg];
   }
   __syncthreads();
   DTC_PT(1, b, 4);
