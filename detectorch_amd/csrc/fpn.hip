@@ -244,28 +244,30 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_distribute_kernel(Fpn
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Fast path: top_n <= 1024, every input list already in score order (the NMS output) or no scores at all (mask branch).
-// Thread r OWNS output rank r: box, score, level and position stay in its registers from the merge to the last store -- the
+// Fast path: top_n <= 2048, every input list already in score order (the NMS output) or no scores at all (mask branch).
+// Thread t OWNS output ranks t (and t + 1024 when top_n > 1024): box, score, level and position stay in its registers from the merge to the last store -- the
 // general kernel above round-trips them through global memory five times (~3 us each, one workgroup per image, nothing
 // else to hide it behind) -- the list merge runs its binary searches in lock-step (all (element, other list) pairs of a
 // thread advance together: ten dependent LDS reads in total instead of two hundred), and the visiting order is written by
 // the owner straight to its sorted slot.  Measured on MI355X (batch 8, 5 x 1000 -> 1000): 51 -> see profiles/r02_*.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kFastMaxTop = 1024;
+constexpr int kFastMaxTop = 2048;      // R = 1: top_n <= 1024 (one output rank per thread), R = 2: <= 2048 (BASELINE cfg5's 2000)
 constexpr int kOrderBuckets = 512;     // visiting-order key >> 23 = (level:3 | band:6)
-constexpr int kFastHdrBytes = 2 * kFastMaxTop * 4 + 2 * kOrderBuckets * 4;
+constexpr int fast_hdr_bytes(int R) { return 2 * R * kFpnThreads * 4 + 2 * kOrderBuckets * 4; }
 
+template <int R>   // output ranks per thread: thread t owns ranks rr * kFpnThreads + t, rr < R
 __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams p, int n_max) {
+  constexpr int kTop = R * kFpnThreads;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* k32 = reinterpret_cast<uint32_t*>(smem);                       // [1024]  order keys, bucket by bucket (later)
-  int* src_of_rank = reinterpret_cast<int*>(smem) + kFastMaxTop;             // [1024]
-  uint32_t* bstart = reinterpret_cast<uint32_t*>(smem) + 2 * kFastMaxTop;    // [512]   visiting order: bucket histogram -> start
+  uint32_t* k32 = reinterpret_cast<uint32_t*>(smem);                       // [kTop]  order keys, bucket by bucket (later)
+  int* src_of_rank = reinterpret_cast<int*>(smem) + kTop;                    // [kTop]
+  uint32_t* bstart = reinterpret_cast<uint32_t*>(smem) + 2 * kTop;           // [512]   visiting order: bucket histogram -> start
   uint32_t* bcur = bstart + kOrderBuckets;                                   // [512]   members placed so far
-  uint64_t* kbuf = reinterpret_cast<uint64_t*>(smem + kFastHdrBytes);        // [2 * n_max] input keys, then merge outputs
+  uint64_t* kbuf = reinterpret_cast<uint64_t*>(smem + fast_hdr_bytes(R));    // [n_max + (L_in - 1) * top_n] input keys, then merge outputs
   __shared__ uint32_t bwsum[kOrderBuckets / 64];
   __shared__ int cnt_s[kFpnMaxLevels];
   __shared__ int l_off[kFpnMaxLevels], l_len[kFpnMaxLevels];
-  __shared__ int wave_cnt[kFpnMaxLevels][kFpnThreads / 64];
+  __shared__ int wave_cnt[kFpnMaxLevels][R * kFpnThreads / 64];              // per (level, rank-wave): rank-wave = rr * 16 + wave
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nl_out = p.k_max - p.k_min + 1;
   DTC_PT(p.L_in > 1 ? 0 : 1, b, 0);
@@ -326,62 +328,88 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams
       __syncthreads();
       scratch += npairs * p.top_n;
     }
-    if (tid < m) src_of_rank[tid] = (int)desc_key_index(kbuf[l_off[0] + tid]);
+    for (int r = tid; r < m; r += kFpnThreads) src_of_rank[r] = (int)desc_key_index(kbuf[l_off[0] + r]);
     __syncthreads();
   }
   DTC_PT(p.L_in > 1 ? 0 : 1, b, 1);
   // ---- rank r: roi, level, position inside its level -- all in registers from here on ---------------------------------
-  const int r = tid;
-  int lvl = -1;
-  float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
-  float score = 0.f;
-  if (r < m) {
-    const int src = merge ? src_of_rank[r] : r;
-    int l = 0;
+  constexpr int kRW = kFpnThreads / 64;                                        // waves per round of ranks
+  int lvl[R], my_before[R];
+  float4 bx[R];
+  float score[R];
+  uint32_t key[R];
 #pragma unroll
-    for (int q = 1; q < kFpnMaxLevels; q++) if (q < p.L_in && src >= in_off[q]) l = q;
-    bx = reinterpret_cast<const float4*>(boxes)[(size_t)l * p.P + (src - in_off[l])];
-    if (p.in_scores) score = p.in_scores[((size_t)b * p.L_in + l) * p.P + (src - in_off[l])];
-    lvl = fpn_level(bx.x, bx.y, bx.z, bx.w, p.k_min, p.k_max) - p.k_min;
+  for (int rr = 0; rr < R; rr++) {
+    const int r = rr * kFpnThreads + tid;
+    lvl[rr] = -1; my_before[rr] = 0;
+    bx[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+    score[rr] = 0.f;
+    if (r < m) {
+      const int src = merge ? src_of_rank[r] : r;
+      int l = 0;
+#pragma unroll
+      for (int q = 1; q < kFpnMaxLevels; q++) if (q < p.L_in && src >= in_off[q]) l = q;
+      bx[rr] = reinterpret_cast<const float4*>(boxes)[(size_t)l * p.P + (src - in_off[l])];
+      if (p.in_scores) score[rr] = p.in_scores[((size_t)b * p.L_in + l) * p.P + (src - in_off[l])];
+      lvl[rr] = fpn_level(bx[rr].x, bx[rr].y, bx[rr].z, bx[rr].w, p.k_min, p.k_max) - p.k_min;
+    }
   }
-  int my_before = 0;
-  for (int l = 0; l < nl_out; l++) {                                           // np.where(lvls == lvl)[0] is ascending (:123)
-    const uint64_t mk = __ballot(lvl == l);
-    if (lane == 0) wave_cnt[l][wv] = __builtin_popcountll(mk);
-    if (lvl == l) my_before = __builtin_popcountll(mk & ((1ull << lane) - 1ull));
-  }
-  // order key for the RoIAlign visiting order (see the general kernel): level | band | x, all in feature pixels
-  uint32_t key = 0xffffffffu;
-  if (r < p.top_n) {
-    const uint32_t yc = (uint32_t)fminf(fmaxf((bx.y + bx.w) * 0.5f, 0.f), 65535.f);
-    const uint32_t xc = (uint32_t)fminf(fmaxf((bx.x + bx.z) * 0.5f, 0.f), 65535.f);
-    const uint32_t lv4 = lvl < 0 ? 15u : (uint32_t)lvl;
-    const uint32_t fs = min((uint32_t)p.k_min + lv4, 15u);
-    const uint32_t band = min((yc >> fs) >> p.band_log2, 63u), xf = min(xc >> fs, 4095u);
-    key = (min(lv4, 7u) << 29) | (((band << 12) | xf) << 11) | (uint32_t)r;
+#pragma unroll
+  for (int rr = 0; rr < R; rr++) {
+    for (int l = 0; l < nl_out; l++) {                                         // np.where(lvls == lvl)[0] is ascending (:123)
+      const uint64_t mk = __ballot(lvl[rr] == l);
+      if (lane == 0) wave_cnt[l][rr * kRW + wv] = __builtin_popcountll(mk);
+      if (lvl[rr] == l) my_before[rr] = __builtin_popcountll(mk & ((1ull << lane) - 1ull));
+    }
+    // order key for the RoIAlign visiting order (see the general kernel): level | band | x, all in feature pixels
+    const int r = rr * kFpnThreads + tid;
+    key[rr] = 0xffffffffu;
+    if (r < p.top_n) {
+      const uint32_t yc = (uint32_t)fminf(fmaxf((bx[rr].y + bx[rr].w) * 0.5f, 0.f), 65535.f);
+      const uint32_t xc = (uint32_t)fminf(fmaxf((bx[rr].x + bx[rr].z) * 0.5f, 0.f), 65535.f);
+      const uint32_t lv4 = lvl[rr] < 0 ? 15u : (uint32_t)lvl[rr];
+      const uint32_t fs = min((uint32_t)p.k_min + lv4, 15u);
+      const uint32_t band = min((yc >> fs) >> p.band_log2, 63u), xf = min(xc >> fs, 4095u);
+      key[rr] = (min(lv4, 7u) << 29) | (((band << 12) | xf) << 11) | (uint32_t)r;   // r < 2048: 11 bits
+    }
   }
   __syncthreads();                                                             // src_of_rank / sc reads done; wave_cnt complete
   if (tid < kOrderBuckets) { bstart[tid] = 0u; bcur[tid] = 0u; }
-  int lvl_tot[kFpnMaxLevels], dst = -1;
+  int lvl_tot[kFpnMaxLevels], dst[R];
+#pragma unroll
+  for (int rr = 0; rr < R; rr++) dst[rr] = -1;
   {
-    int acc = 0, base = 0;
+    // ranks ascend with the rank-wave index g = rr * kRW + wave, then with the lane: members of level l in front of mine =
+    // all of the rank-waves before mine + the lanes before me; levels are laid out one after the other (:123-127)
+    int acc = 0;
     for (int l = 0; l < nl_out; l++) {
-      int t = 0, bw = 0;
-      for (int q = 0; q < kFpnThreads / 64; q++) { const int c = wave_cnt[l][q]; if (q < wv) bw += c; t += c; }
+      int t = 0, before[R];
+#pragma unroll
+      for (int rr = 0; rr < R; rr++) before[rr] = 0;
+      for (int g = 0; g < R * kRW; g++) {
+        const int c = wave_cnt[l][g];
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) if (g < rr * kRW + wv) before[rr] += c;
+        t += c;
+      }
       lvl_tot[l] = t;
-      if (l == lvl) base = acc + bw;
+#pragma unroll
+      for (int rr = 0; rr < R; rr++) if (l == lvl[rr]) dst[rr] = acc + before[rr] + my_before[rr];   // argsort(concat(idx_lvl)) == inverse permutation
       acc += t;
     }
-    if (lvl >= 0) dst = base + my_before;                                      // :127 argsort(concat(idx_lvl)) == inverse permutation
   }
-  if (r < p.top_n) {
-    const size_t g = (size_t)b * p.top_n + r;
-    float* o = p.rois5 + g * 5;
-    o[0] = (float)b; o[1] = bx.x; o[2] = bx.y; o[3] = bx.z; o[4] = bx.w;
-    p.roi_levels[g] = lvl;
-    if (p.roi_scores) p.roi_scores[g] = score;
-    p.idx_restore[g] = dst;
-    if (dst >= 0) reinterpret_cast<float4*>(p.rois_by_level)[(size_t)b * p.top_n + dst] = bx;
+#pragma unroll
+  for (int rr = 0; rr < R; rr++) {
+    const int r = rr * kFpnThreads + tid;
+    if (r < p.top_n) {
+      const size_t g = (size_t)b * p.top_n + r;
+      float* o = p.rois5 + g * 5;
+      o[0] = (float)b; o[1] = bx[rr].x; o[2] = bx[rr].y; o[3] = bx[rr].z; o[4] = bx[rr].w;
+      p.roi_levels[g] = lvl[rr];
+      if (p.roi_scores) p.roi_scores[g] = score[rr];
+      p.idx_restore[g] = dst[rr];
+      if (dst[rr] >= 0) reinterpret_cast<float4*>(p.rois_by_level)[(size_t)b * p.top_n + dst[rr]] = bx[rr];
+    }
   }
   if (tid < nl_out) p.level_counts[b * nl_out + tid] = lvl_tot[tid];
   if (tid == 0) p.n_out[b] = m;
@@ -392,9 +420,9 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams
   // (250 broadcast ds_read_b128 + 1000 compares each: the longest phase of the kernel); the key's top 9 bits (level | band)
   // name one of a few dozen populated buckets of ~75 RoIs, so: histogram -> exclusive scan -> members placed bucket by
   // bucket (any order) -> each thread counts the smaller keys of ITS bucket only.  rank = bucket start + that count.
-  const bool valid = r < p.top_n;
-  const uint32_t bucket = key >> 23;
-  if (valid) atomicAdd(&bstart[bucket], 1u);
+#pragma unroll
+  for (int rr = 0; rr < R; rr++)
+    if (rr * kFpnThreads + tid < p.top_n) atomicAdd(&bstart[key[rr] >> 23], 1u);
   __syncthreads();
   uint32_t hv = 0, incl = 0;
   if (tid < kOrderBuckets) {
@@ -410,19 +438,27 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams
     bstart[tid] = base + incl - hv;
   }
   __syncthreads();
-  uint32_t start = 0;
-  if (valid) { start = bstart[bucket]; k32[start + atomicAdd(&bcur[bucket], 1u)] = key; }
+  uint32_t start[R];
+#pragma unroll
+  for (int rr = 0; rr < R; rr++) {
+    start[rr] = 0;
+    if (rr * kFpnThreads + tid < p.top_n) { const uint32_t bk = key[rr] >> 23; start[rr] = bstart[bk]; k32[start[rr] + atomicAdd(&bcur[bk], 1u)] = key[rr]; }
+  }
   __syncthreads();
-  if (valid) {
-    const int cnt = (int)bcur[bucket];
-    int rank = (int)start;
-    for (int j = 0; j < cnt; j++) rank += k32[start + j] < key ? 1 : 0;
-    const size_t g = (size_t)b * p.top_n + rank;
-    p.roi_order[g] = b * p.top_n + r;
-    if (p.roi_desc) {
-      float4* d = reinterpret_cast<float4*>(p.roi_desc + g * 8);
-      d[0] = make_float4((float)b, bx.x, bx.y, bx.z);
-      d[1] = make_float4(bx.w, (float)lvl, (float)(b * p.top_n + r), 0.f);
+#pragma unroll
+  for (int rr = 0; rr < R; rr++) {
+    const int r = rr * kFpnThreads + tid;
+    if (r < p.top_n) {
+      const int cnt = (int)bcur[key[rr] >> 23];
+      int rank = (int)start[rr];
+      for (int j = 0; j < cnt; j++) rank += k32[start[rr] + j] < key[rr] ? 1 : 0;
+      const size_t g = (size_t)b * p.top_n + rank;
+      p.roi_order[g] = b * p.top_n + r;
+      if (p.roi_desc) {
+        float4* d = reinterpret_cast<float4*>(p.roi_desc + g * 8);
+        d[0] = make_float4((float)b, bx[rr].x, bx[rr].y, bx[rr].z);
+        d[1] = make_float4(bx[rr].w, (float)lvl[rr], (float)(b * p.top_n + r), 0.f);
+      }
     }
   }
   DTC_PT(p.L_in > 1 ? 0 : 1, b, 3);
@@ -463,16 +499,22 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
   const bool fast = post_nms_top_n <= dtc::kFastMaxTop && in_stride <= 1024 && n_max <= 8192 &&
                     (!in_scores || inputs_sorted) && !no_fast;
   if (fast) {
-    // k32 + src_of_rank + order buckets (12 KB) + input keys (n_max) + merge outputs (<= n_max): 8 B each
-    const size_t fsm = (size_t)dtc::kFastHdrBytes + (size_t)(in_scores && n_in_levels > 1 ? 2 * n_max : 0) * 8 + 16;
-    static std::once_flag once;
-    static hipError_t arc = hipSuccess;
-    std::call_once(once, [] { arc = hipFuncSetAttribute(reinterpret_cast<const void*>(dtc::fpn_collect_fast_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); });
-    if (arc != hipSuccess) return DTC_ELAUNCH;
-    hipLaunchKernelGGL(dtc::fpn_collect_fast_kernel, dim3(batch), dim3(dtc::kFpnThreads), fsm, reinterpret_cast<hipStream_t>(stream), p, (int)n_max);
-    DTC_CHECK_LAUNCH();
-    return DTC_OK;
+    // k32 + src_of_rank + order buckets + input keys (n_max) + merge outputs (one top_n-strided list per pairwise merge:
+    // L - 1 of them): 8 B each
+    const int R = post_nms_top_n <= dtc::kFpnThreads ? 1 : 2;
+    const size_t fsm = (size_t)dtc::fast_hdr_bytes(R) +
+                       (size_t)(in_scores && n_in_levels > 1 ? n_max + (long long)(n_in_levels - 1) * post_nms_top_n : 0) * 8 + 16;
+    if (fsm <= 150 * 1024) {
+      if (R == 1) {
+        DTC_RAISE_LDS_ONCE(dtc::fpn_collect_fast_kernel<1>, 152 * 1024);
+        hipLaunchKernelGGL(dtc::fpn_collect_fast_kernel<1>, dim3(batch), dim3(dtc::kFpnThreads), fsm, reinterpret_cast<hipStream_t>(stream), p, (int)n_max);
+      } else {
+        DTC_RAISE_LDS_ONCE(dtc::fpn_collect_fast_kernel<2>, 152 * 1024);
+        hipLaunchKernelGGL(dtc::fpn_collect_fast_kernel<2>, dim3(batch), dim3(dtc::kFpnThreads), fsm, reinterpret_cast<hipStream_t>(stream), p, (int)n_max);
+      }
+      DTC_CHECK_LAUNCH();
+      return DTC_OK;
+    }
   }
   hipLaunchKernelGGL(dtc::fpn_collect_distribute_kernel, dim3(batch), dim3(dtc::kFpnThreads), smem,
                      reinterpret_cast<hipStream_t>(stream), p);

@@ -470,7 +470,9 @@ DTC_API int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg,
   DTC_CHECK_LAUNCH();
   // few long segments whose matrix fits LDS (the RPN call): the LDS walk (see the kernel); else the one-wave walk
   const size_t lds_need = ((size_t)ncb * 64 * ncb + (size_t)ncb * 64) * sizeof(uint64_t);
-  if (n_seg <= 512 && ncb >= 4 && ncb <= 16 && (ncb & 1) == 0 && lds_need <= 150 * 1024) {
+  // (each workgroup of the LDS walk holds ~136 KB: one per CU.  Up to 160 segments -- RPN calls up to batch 32 -- are resident
+  // together; the hundreds of ~10-candidate class segments of a detection batch are better off in the one-wave kernel.)
+  if (n_seg <= 160 && ncb >= 4 && ncb <= 16 && (ncb & 1) == 0 && lds_need <= 150 * 1024) {
     if (lds_need > 48 * 1024) DTC_RAISE_LDS_ONCE(dtc::nms_reduce_lds_kernel, 152 * 1024);   // + 2 KB static
     hipLaunchKernelGGL(dtc::nms_reduce_lds_kernel, dim3(n_seg), dim3(dtc::kReduceLdsThreads), lds_need, s, mask, diag_t, counts,
                        n_stride, ncb, max_keep, keep, keep_stride, keep_count);

@@ -46,9 +46,13 @@ def test_level_boundaries_golden_and_blobs(hip):
     assert blobs["rois_idx_restore_int32"].dtype == np.int32
 
 
-def test_collect_distribute_batched_vs_oracle(hip, oracle):
+@pytest.mark.parametrize("sorted_inputs", [False, True])
+@pytest.mark.parametrize("top_n", [1000, 1500, 2000])
+def test_collect_distribute_batched_vs_oracle(hip, oracle, top_n, sorted_inputs):
+    """Unsorted level lists take the general kernel (sort); lists in score order -- what the NMS stage emits -- the merge
+    kernel: top_n 1000 = one output rank per thread, 1500 / 2000 (BASELINE cfg5's collect size) = two."""
     B, L, P = 3, 5, 1000
-    rs = synth.rng(4, 50)
+    rs = synth.rng(4, 50 + (top_n - 1000))
     boxes = np.zeros((B, L, P, 4), np.float32)
     scores = np.zeros((B, L, P), np.float32)
     counts = rs.randint(0, P + 1, (B, L)).astype(np.int32)
@@ -59,11 +63,19 @@ def test_collect_distribute_batched_vs_oracle(hip, oracle):
         for l in range(L):
             boxes[b, l, :counts[b, l]] = synth.make_rois(rs, counts[b, l])
             scores[b, l] = sc[l]
-    res = hip.fpn_collect_distribute(cu(boxes), cu(scores), cu(counts), 1000, 2, 5)
+            if sorted_inputs:
+                scores[b, l, :counts[b, l]] = np.sort(sc[l, :counts[b, l]])[::-1]
+    res = hip.fpn_collect_distribute(cu(boxes), cu(scores), cu(counts), top_n, 2, 5, inputs_sorted=sorted_inputs)
+    order, desc = res["roi_order"].cpu().numpy(), res["roi_desc"].cpu().numpy()
     for b in range(B):
+        # the RoIAlign visiting order is a permutation of the image's rows and the packed descriptors repeat them
+        assert sorted(order[b].tolist()) == list(range(b * top_n, (b + 1) * top_n))
+        r5, lvb = res["rois5"][b].cpu().numpy(), res["roi_levels"][b].cpu().numpy()
+        rows = order[b] - b * top_n
+        assert np.array_equal(desc[b, :, :5], r5[rows]) and np.array_equal(desc[b, :, 5], lvb[rows]) and np.array_equal(desc[b, :, 6], order[b])
         rc = np.concatenate([boxes[b, l, :counts[b, l]] for l in range(L)])
         sc = np.concatenate([scores[b, l, :counts[b, l]] for l in range(L)])
-        top, tsc, _ = oracle.collect(rc, sc, 1000)
+        top, tsc, _ = oracle.collect(rc, sc, top_n)
         outs, restore, lv = oracle.distribute(top, 2, 5)
         n = int(res["n_out"][b])
         assert n == top.shape[0]
