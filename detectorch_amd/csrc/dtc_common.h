@@ -97,13 +97,20 @@ constexpr int kPtKernels = 4, kPtBlocks = 64, kPtMarks = 24;
 // run out of order with them (round 2: stale radix-select histograms after `replay B, eager A, eager B, replay A`).
 template <int kUnused = 0>
 __global__ void zero_words_kernel(uint32_t* p, size_t n_words) {
+  // 16-byte stores where the buffer allows it (the radix-select histograms of a batch are 1.3 MB: a quarter of the workgroups)
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_words) p[i] = 0u;
+  const size_t n4 = (reinterpret_cast<uintptr_t>(p) & 15) == 0 ? n_words >> 2 : 0;
+  if (i < n4) reinterpret_cast<uint4*>(p)[i] = make_uint4(0u, 0u, 0u, 0u);
+  const size_t tail = 4 * n4 + i;                       // the first threads also clear what the 16-byte part leaves over
+  if (i < n_words - 4 * n4 && n4 == 0) p[tail] = 0u;    // unaligned buffer: one word per thread (grid sized for it below)
+  else if (n4 != 0 && i < (n_words & 3)) p[tail] = 0u;
 }
 inline int zero_async(void* p, size_t bytes, hipStream_t s) {   // bytes: multiple of 4, p 4-byte aligned
   if (bytes == 0) return DTC_OK;
   const size_t n = bytes / 4;
-  hipLaunchKernelGGL(zero_words_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), n);
+  const bool al16 = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  const size_t threads = al16 ? (n >> 2) + 3 : n;      // >= the 16-byte stores, and >= the (< 4) left-over words
+  hipLaunchKernelGGL(zero_words_kernel<0>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), n);
   return hipGetLastError() == hipSuccess ? DTC_OK : DTC_ELAUNCH;
 }
 

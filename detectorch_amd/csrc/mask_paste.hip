@@ -191,9 +191,9 @@ __global__ __launch_bounds__(kPasteThreads) void mask_paste_kernel(PasteParams p
     const int* eb = t.eb; const int* r = t.r;
     int w = eb[2] - eb[0] + 1, h = eb[3] - eb[1] + 1;      // :197-198
     w = max(w, 1); h = max(h, 1);                          // :199-200
-    if (band == 0 && tid < 4) {
-      p.mask_boxes[((size_t)b * p.max_out + d) * 4 + tid] = eb[tid];
-      p.mask_rects[((size_t)b * p.max_out + d) * 4 + tid] = r[tid];
+    if (band == 0 && tid < 4) {            // selects, not eb[tid]: a dynamic index would put the two arrays in scratch memory
+      p.mask_boxes[((size_t)b * p.max_out + d) * 4 + tid] = tid == 0 ? eb[0] : tid == 1 ? eb[1] : tid == 2 ? eb[2] : eb[3];
+      p.mask_rects[((size_t)b * p.max_out + d) * 4 + tid] = tid == 0 ? r[0] : tid == 1 ? r[1] : tid == 2 ? r[2] : r[3];
     }
     if (band == 0 && tid == 0) p.mask_offsets[(size_t)b * p.max_out + d] = offset;
     const int rw = r[2] - r[0], rh = r[3] - r[1];

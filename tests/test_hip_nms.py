@@ -61,6 +61,18 @@ def test_heavy_overlap_and_ties(hip, oracle):
     assert np.array_equal(hip.nms(torch.from_numpy(d).cuda(), 0.6).cpu().numpy(), oracle.nms(d, 0.6))
 
 
+def test_quotient_on_the_threshold_and_degenerate_boxes(hip, oracle):
+    """The mask kernel decides `inter / union >= thresh` from the sign of inter - thresh * union and divides only inside a
+    2^-21 band around zero (and for union <= 0 / thresh <= 0): pairs whose quotient equals the threshold exactly or misses it by
+    a hair, thresholds that are not representable, non-positive thresholds, zero-area and inverted boxes.  (The oracle is pinned
+    to the reference's Cython on the same set: tests/test_oracle_ref.py.)"""
+    from conftest import BOUNDARY_THRESHOLDS, threshold_boundary_dets
+    d = threshold_boundary_dets()
+    for thr in BOUNDARY_THRESHOLDS:
+        keep = hip.nms(torch.from_numpy(d).cuda(), thr).cpu().numpy()
+        assert np.array_equal(keep, oracle.nms(d, thr)), thr
+
+
 def test_segmented_sorted_with_max_keep(hip, oracle):
     # 5 "levels" with ragged counts, already score-sorted (the RPN case), keep[:post_nms_top_n]
     counts = [1000, 700, 64, 1, 0]

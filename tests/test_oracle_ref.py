@@ -41,6 +41,15 @@ def test_nms_vs_reference_cython(oracle, ref, n, thr):
     assert np.array_equal(oracle.nms(dets, thr), cn.nms(dets, np.float32(thr)))
 
 
+def test_nms_threshold_boundary_set_vs_reference_cython(oracle, ref):
+    """IoU exactly on / a hair off the threshold, non-positive thresholds, degenerate boxes: oracle == the reference's Cython."""
+    from conftest import BOUNDARY_THRESHOLDS, threshold_boundary_dets
+    cn, _ = ref.load_ref_cython()
+    d = threshold_boundary_dets()
+    for thr in BOUNDARY_THRESHOLDS:
+        assert np.array_equal(oracle.nms(d, thr), cn.nms(d, np.float32(thr))), thr
+
+
 @pytest.mark.parametrize("method", ["hard", "linear", "gaussian"])
 def test_soft_nms_vs_reference_cython(oracle, ref, method):
     cn, _ = ref.load_ref_cython()
