@@ -87,10 +87,20 @@ __global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4*
   const int ncg = (ncb + kMaskWaves - 1) / kMaskWaves;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float4* B = boxes + (size_t)s * n_stride;
-  for (int t = blockIdx.x; t < ncb * ncg; t += gridDim.x) {
-    const int rb = t / ncg, cg = t - rb * ncg;
+  // only the tile groups that reach the diagonal or lie above it are enumerated: row block rb has ncg - rb / kMaskWaves of them
+  // (a 16 x 16-block segment: 40 of 64 -- the other 24 used to be workgroups that were launched to return at once)
+  const int full = ncb / kMaskWaves;                          // row-block bands of kMaskWaves with the same group count
+  int n_upper = 0;
+  for (int q = 0; q <= full; q++) n_upper += (ncg - q) * min(kMaskWaves, ncb - q * kMaskWaves);
+  for (int t = blockIdx.x; t < n_upper; t += gridDim.x) {
+    int rb = 0, rem = t;
+    for (int q = 0; q <= full; q++) {                         // uniform: at most ncb / 4 + 1 steps
+      const int per = ncg - q, rows = min(kMaskWaves, ncb - q * kMaskWaves);
+      if (rem < per * rows) { rb = q * kMaskWaves + rem / per; rem -= (rem / per) * per; break; }
+      rem -= per * rows;
+    }
+    const int cg = rb / kMaskWaves + rem;
     const int cb0 = cg * kMaskWaves;
-    if (cb0 + kMaskWaves - 1 < rb) continue;                  // whole group below the diagonal (uniform)
     __syncthreads();                                          // previous tile's readers are done with rbox_s
     if (wv == 0) {
       const int row = rb * 64 + lane;
@@ -461,8 +471,17 @@ DTC_API int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg,
                                                  dtc::align_up((size_t)n_seg * n_stride * ((n_stride + 63) / 64) * sizeof(uint64_t), 256));
   // workgroups per segment: all tile groups when there are few segments (RPN: 40 x 64), a handful when there are many
   // (detections: 640 class segments, mostly one tile each)
-  const int groups = ncb * ((ncb + dtc::kMaskWaves - 1) / dtc::kMaskWaves);
-  int gx = 4096 / n_seg;
+  // (tile groups on or above the diagonal of a full segment: see the kernel)
+  const int ncg = (ncb + dtc::kMaskWaves - 1) / dtc::kMaskWaves;
+  int groups = 0;
+  for (int q = 0; q <= ncb / dtc::kMaskWaves; q++) {
+    const int rows = ncb - q * dtc::kMaskWaves < dtc::kMaskWaves ? ncb - q * dtc::kMaskWaves : dtc::kMaskWaves;
+    groups += (ncg - q) * (rows > 0 ? rows : 0);
+  }
+  // about 2000 workgroups per launch: every one of a few long segments' groups, ONE workgroup for each of many short segments
+  // (the 640 class segments of a detection batch hold ~10 candidates = one tile each: 6 workgroups per segment were 3200
+  // launched to return at once)
+  int gx = 2048 / n_seg;
   if (gx < 1) gx = 1;
   if (gx > groups) gx = groups;
   hipLaunchKernelGGL(dtc::nms_mask_kernel, dim3(gx, 1, n_seg), dim3(64 * dtc::kMaskWaves), 0, s,
