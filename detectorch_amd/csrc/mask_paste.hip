@@ -2,10 +2,11 @@
 // (lib/utils/result_utils.py:170-214): D2H of the full [D,81,M,M] mask tensor (80/81 of it unused), cv2.resize of the
 // zero-padded (M+2)^2 mask to the box size, `> 0.5`, paste into a full-frame uint8 image.
 //
-// One workgroup per detection.  Only the class-specific channel (:192) is read; the padded mask is staged in LDS; the
+// One workgroup per (detection, band of rows) -- band 0 by the detection's own workgroup, further bands of large boxes by
+// helper workgroups (see the kernel).  Only the class-specific channel (:192) is read; the padded mask is staged in LDS; the
 // output is the binarised mask restricted to the paste rectangle (:204-214) -- the only part of im_mask that is not
 // zero -- written back-to-back into one byte buffer per image (offsets are emitted), so nothing full-frame is ever
-// materialised.  RLE encoding (:217-220, pycocotools) stays on the host.
+// materialised.  RLE encoding (:217-220, pycocotools): dtc_mask_rle (mask_rle.hip) on the same crops.
 //
 // PARITY NOTE: the interpolation is OpenCV's cv2.resize(CV_32F, INTER_LINEAR), which is not part of the reference tree
 // (un-vendored, unpinned).  It is restated from OpenCV's documented rule, identically in oracle/oracle.c

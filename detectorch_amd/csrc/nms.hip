@@ -2,13 +2,15 @@
 //
 // Segmented: one launch handles every (image, FPN level) or (image, class) segment of a batch.
 //   1. segment_sort_desc   : per segment, (score desc, index asc) order through the shared 64-bit key (block_sort.h)  [:45]
-//   2. nms_mask            : 64x64 tiles of the suppression matrix; lane <-> column box, the 64 row boxes are broadcast
-//                            through SGPRs (v_readlane with a constant lane), the 64-lane compare is collected with
-//                            __ballot into one 64-bit word per row.  IoU in the reference's float32 operation order
-//                            [:76-84]: inter / (iarea + areas[j] - inter) >= thresh, IEEE division, no contraction.
-//   3. nms_reduce          : one wavefront per segment walks the rows in score order; the in-block dependency chain is
-//                            resolved on the scalar unit over KEPT rows only (ctz loop), rows of kept boxes are OR-ed
-//                            into a register-resident `removed` bit-vector (lane l owns words l, l+64, ...).
+//   2. nms_mask            : 64x64 tiles of the suppression matrix (only those on or above the diagonal are enumerated);
+//                            lane <-> column box, the row boxes are broadcast from LDS, the 64-lane compare is collected
+//                            with a ballot into one 64-bit word per row.  IoU in the reference's float32 operation order
+//                            [:76-84]: inter / (iarea + areas[j] - inter) >= thresh -- decided from the sign of
+//                            inter - thresh * union, with the IEEE division only inside a 2^-21 band (see the kernel).
+//   3. nms_reduce          : one wavefront per segment walks the row blocks in score order; the in-block dependency chain
+//                            is resolved as a wave-wide fixed point on the transposed diagonal tile, rows of kept boxes are
+//                            OR-ed into an LDS-resident `removed` bit-vector.  nms_reduce_lds: the same walk from an LDS
+//                            copy of the whole matrix, for few long segments (the RPN call).
 // Output order: positions in score order (what `keep[:post_nms_top_n]` needs, generate_proposals.py:117); dtc_nms()
 // additionally maps back to ascending original indices like np.where(suppressed == 0)[0]  [:87].
 #include <stdlib.h>
