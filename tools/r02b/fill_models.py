@@ -1,0 +1,89 @@
+"""Development aid (offline, CPU): L2->L1 line fills per (RoI, channel) of the FPN box-head RoIAlign launch under different
+staging structures, on the bench's RoI distribution (tools/r02b/gen_rois.py writes /tmp/rois_<i>.npy).  fp32 NCHW maps, 128-byte
+lines.  Models:
+  compulsory      every line any window touches, once per (image, channel)                       -- the floor
+  roi             one RoI's window per workgroup (round 1: roi_align_fwd_lds)
+  cluster K       K consecutive RoIs of the visiting order merged greedily (roi_align_fwd_tile, merge rule 250 %)
+  band H          a workgroup owns a band of H feature rows of one level x a channel block and sweeps it in x with a sliding
+                  LDS window: it stages rows [band start, band end + halo) once per channel, where the halo is what the windows
+                  of the RoIs assigned to the band (by their top row) reach below it
+Usage: python tools/r02b/gen_rois.py 4 && python tools/r02b/fill_models.py 4"""
+import sys
+import numpy as np
+sys.path.insert(0, __file__.rsplit("/", 3)[0] + "/tools/r02")
+from analyze_clusters import window, SHAPES
+
+
+def lines_of(row, x0, x1, W):
+    b0, b1 = (row * W + x0) * 4, (row * W + x1) * 4 + 3
+    return range(b0 >> 7, (b1 >> 7) + 1)
+
+
+def main(n_img):
+    tot = dict(rois=0, compulsory=0, roi=0)
+    clus = {5: 0, 10: 0, 20: 0}
+    bands = {8: 0, 16: 0, 32: 0, 64: 0}
+    band_lds = {h: 0 for h in bands}
+    for i in range(n_img):
+        d = np.load("/tmp/rois_%d.npy" % i)
+        wins = [window(r) for r in d]
+        tot["rois"] += len(wins)
+        touched = [set() for _ in SHAPES]
+        for w in wins:
+            _, lvl, x0, x1, y0, y1 = w
+            W = SHAPES[lvl][1]
+            for row in range(y0, y1 + 1):
+                ls = lines_of(row, x0, x1, W)
+                touched[lvl].update(ls)
+                tot["roi"] += len(ls)
+        tot["compulsory"] += sum(len(t) for t in touched)
+        # clusters of K consecutive RoIs (visiting order), union bounding patch, 4-pixel aligned columns, merge rule 250 %
+        for K in clus:
+            for g0 in range(0, len(wins), K):
+                grp = wins[g0:g0 + K]
+                k = 0
+                while k < len(grp):
+                    a = grp[k]; x0, x1, y0, y1 = a[2], a[3], a[4], a[5]; cnt = 1
+                    spx = (y1 - y0 + 1) * (x1 - x0 + 1)
+                    while k + cnt < len(grp):
+                        n = grp[k + cnt]
+                        if n[1] != a[1]: break
+                        ux0, ux1, uy0, uy1 = min(x0, n[2]), max(x1, n[3]), min(y0, n[4]), max(y1, n[5])
+                        npx = (n[5] - n[4] + 1) * (n[3] - n[2] + 1); upx = (uy1 - uy0 + 1) * (ux1 - ux0 + 1)
+                        if upx * 100 > (spx + npx) * 250 or upx > 2048: break
+                        x0, x1, y0, y1 = ux0, ux1, uy0, uy1; cnt += 1; spx += npx
+                    W = SHAPES[a[1]][1]
+                    xa0, xa1 = x0 & ~3, (x1 | 3)
+                    for row in range(y0, y1 + 1):
+                        clus[K] += len(lines_of(row, xa0, min(xa1, W - 1), W))
+                    k += cnt
+        # band sweeps: RoI -> band of its window's top row; the band stages full-width rows [H*b, max window bottom]
+        for H in bands:
+            for lvl, (Hl, Wl) in enumerate(SHAPES):
+                lw = [w for w in wins if w[1] == lvl]
+                if not lw: continue
+                nb = -(-Hl // H)
+                bottom = [-1] * nb
+                xs = [[Wl, -1] for _ in range(nb)]
+                for w in lw:
+                    b = w[4] // H
+                    bottom[b] = max(bottom[b], w[5])
+                    xs[b][0] = min(xs[b][0], w[2]); xs[b][1] = max(xs[b][1], w[3])
+                for b in range(nb):
+                    if bottom[b] < 0: continue
+                    rows = bottom[b] - b * H + 1
+                    band_lds[H] = max(band_lds[H], rows)
+                    for row in range(b * H, bottom[b] + 1):
+                        bands[H] += len(lines_of(row, xs[b][0], xs[b][1], Wl))
+    R = tot["rois"]
+    print("%d images, %d RoIs; line fills per (RoI, channel):" % (n_img, R))
+    print("  compulsory (each touched line once per image and channel)  %.2f" % (tot["compulsory"] / R))
+    print("  one RoI per workgroup                                      %.2f" % (tot["roi"] / R))
+    for K, v in clus.items():
+        print("  clusters of <= %2d consecutive RoIs (merge 250 %%)            %.2f" % (K, v / R))
+    for H, v in bands.items():
+        print("  band sweep, %2d-row bands (+ halo; tallest band %3d rows)     %.2f" % (H, band_lds[H], v / R))
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 2)
