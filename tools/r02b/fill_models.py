@@ -87,3 +87,41 @@ def main(n_img):
 
 if __name__ == "__main__":
     main(int(sys.argv[1]) if len(sys.argv) > 1 else 2)
+
+
+def band_batches(n_img, H=32, Wc=64):
+    """Feasibility numbers of the band sweep: rows a band's LDS window must hold, and how many RoIs a batch holds
+    when the window is a ring of Wc columns and a batch is a run of consecutive RoIs (x-centre order) whose windows fit in it."""
+    rows_hist, batch_sizes, per_band, wide = [], [], [], 0
+    for i in range(n_img):
+        d = np.load("/tmp/rois_%d.npy" % i)
+        wins = [window(r) for r in d]
+        for lvl, (Hl, Wl) in enumerate(SHAPES):
+            lw = [w for w in wins if w[1] == lvl]
+            for b in range(-(-Hl // H)):
+                bw = sorted([w for w in lw if w[4] // H == b], key=lambda w: (w[2] + w[3]))
+                if not bw: continue
+                per_band.append((lvl, len(bw)))
+                rows_hist.append((lvl, max(w[5] for w in bw) - b * H + 1))
+                k = 0
+                while k < len(bw):
+                    xa, n = bw[k][2], 0
+                    while k + n < len(bw):
+                        w = bw[k + n]
+                        xa2 = min(xa, w[2])
+                        if max(x[3] for x in bw[k:k + n + 1]) - xa2 + 1 > Wc: break
+                        xa = xa2; n += 1
+                    if n == 0: wide += 1; n = 1          # a single window wider than the ring: needs its own path
+                    batch_sizes.append((lvl, n)); k += n
+    for lvl in range(4):
+        r = [x for l, x in rows_hist if l == lvl]; bs = [x for l, x in batch_sizes if l == lvl]; pb = [x for l, x in per_band if l == lvl]
+        if not r: continue
+        print("  level %d: bands %3d  RoIs/band mean %5.1f max %3d | window rows mean %4.1f max %3d | RoIs per batch mean %4.1f  (batches with < 4 RoIs: %2.0f %%)"
+              % (lvl, len(r), np.mean(pb), max(pb), np.mean(r), max(r), np.mean(bs), 100.0 * np.mean(np.array(bs) < 4)))
+    print("  windows wider than the %d-column ring: %d" % (Wc, wide))
+
+
+if __name__ == "__main__":
+    for H, Wc in ((32, 64), (32, 128), (16, 64)):
+        print("band sweep feasibility, %d-row bands, ring of %d columns:" % (H, Wc))
+        band_batches(int(sys.argv[1]) if len(sys.argv) > 1 else 2, H, Wc)
