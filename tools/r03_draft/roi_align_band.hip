@@ -31,6 +31,8 @@
 // (7) 16-byte buffer loads + a register pipeline for the staging (scalar loads here); (8) registers: at the 128-VGPR cap of a
 // 1024-thread workgroup this draft spills 92 bytes per lane (-Rpass-analysis=kernel-resource-usage) -- the four make_axis results
 // per lane live across the quad loop; tables (3) remove them.
+#include <string.h>
+
 #include "roi_align_common.h"
 
 namespace dtc {
@@ -229,7 +231,42 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(RoiAlignParam
   }
 }
 
-// explicit instantiation so that the draft is compiled, not just parsed
-template __global__ void roi_align_fwd_band<float, 2>(RoiAlignParams, const BandItem*, int);
-
 }  // namespace dtc
+
+// ---- experiment entry (tools/r03_draft/run_band.py): fp32 NCHW maps, packed descriptors, bins <= 64 ----------------------------
+// ws: [ int n_items | pad to 16 | BandItem items[max_items] ].  Synchronises once to read the item count (an experiment, not a
+// product entry: the product would take the run table from dtc_fpn_collect_distribute and launch without a host round trip).
+extern "C" __attribute__((visibility("default"))) int dtc_draft_roi_align_band(
+    const dtc_feat_level* levels, int n_levels, int channels, const float* roi_desc, int n_rois, int pooled_h, int pooled_w,
+    float* out, void* ws, int max_items, int band_log2, int k_min, int rows_cap, int* n_items_out, void* stream) {
+  using namespace dtc;
+  if (n_levels < 1 || n_levels > DTC_MAX_LEVELS || pooled_h * pooled_w > 64 || (channels & 7) != 0) return DTC_EUNSUPPORTED;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  RoiAlignParams p;
+  memset(&p, 0, sizeof(p));
+  for (int l = 0; l < n_levels; l++) p.lv[l] = levels[l];
+  p.rois = nullptr; p.roi_levels = nullptr; p.roi_order = nullptr; p.roi_desc = roi_desc; p.out = out;
+  p.n_levels = n_levels; p.channels = channels; p.roi_cols = 5; p.n_rois = n_rois; p.pooled_h = pooled_h; p.pooled_w = pooled_w;
+  p.sampling_ratio = 2;
+  int* n_items = reinterpret_cast<int*>(ws);
+  BandItem* items = reinterpret_cast<BandItem*>(reinterpret_cast<unsigned char*>(ws) + 16);
+  if (zero_async(n_items, 16, s) != DTC_OK) return DTC_ELAUNCH;
+  hipLaunchKernelGGL(band_items_kernel, dim3((unsigned)((n_rois + 255) / 256)), dim3(256), 0, s, p, band_log2, k_min, items, n_items, max_items);
+  int n = 0;
+  if (hipMemcpyAsync(&n, n_items, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return DTC_ELAUNCH;
+  if (n_items_out) *n_items_out = n;
+  if (n > max_items) return DTC_EWORKSPACE;
+  if (n == 0) return DTC_OK;
+  constexpr int NQ = 2;
+  const int bins = pooled_h * pooled_w;
+  const size_t lds = (size_t)NQ * rows_cap * kRingCols * 16 + (size_t)kBandWaves * 4 * NQ * bins * 4;
+  if (lds > 158 * 1024) return DTC_EUNSUPPORTED;
+  static bool raised = false;     // experiment code: single-threaded harness
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_band<float, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess) return DTC_ELAUNCH;
+    raised = true;
+  }
+  const int ncg = channels / (4 * NQ);
+  hipLaunchKernelGGL((roi_align_fwd_band<float, NQ>), dim3((unsigned)(n * ncg)), dim3(kBandThreads), lds, s, p, items, rows_cap);
+  return hipGetLastError() == hipSuccess ? DTC_OK : DTC_ELAUNCH;
+}

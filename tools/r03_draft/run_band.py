@@ -1,0 +1,88 @@
+"""Round-3 experiment harness for the band-sweep draft (tools/r03_draft/roi_align_band.hip): builds it into its own shared
+library, runs it on the bench's box-head launch (real descriptors from one eager step of FpnRegionPath), compares the output with
+the product kernel's bit for bit and times both.
+
+    python tools/r03_draft/run_band.py --build      # here (hipcc cross-compiles); the .so travels to the GPU box with gpurun
+    python tools/r03_draft/run_band.py              # on the GPU box
+
+The RoIs of levels the draft is not meant for can be masked out with --level (default: all levels)."""
+import argparse
+import ctypes
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "libband_draft.so")
+
+
+def build():
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-I", os.path.join(ROOT, "detectorch_amd", "csrc"), os.path.join(HERE, "roi_align_band.hip"), "-o", LIB]
+    subprocess.check_call(cmd)
+    print("built", LIB)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--band-log2", type=int, default=5, help="band height in feature rows (log2); the visiting order must use the same")
+    ap.add_argument("--rows-cap", type=int, default=64)
+    a = ap.parse_args()
+    if a.build:
+        return build()
+    os.environ["DTC_FPN_BAND_LOG2"] = str(a.band_log2)       # fpn.hip reads it once: the visiting order is (level, band, x)
+    sys.path.insert(0, ROOT)
+    import torch
+    from detectorch_amd import hip
+    from detectorch_amd.pipeline import FpnRegionPath, synthetic_batch
+    dev = torch.device("cuda", 0)
+    path = FpnRegionPath(a.batch, dev)
+    path.bind(*synthetic_batch(a.batch, dev, seed=3000))
+    path.step(use_graph=False)
+    torch.cuda.synchronize()
+    ref = path.box_feats.clone()                              # the product kernel's output for the same descriptors
+    L = ctypes.CDLL(LIB)
+    p, i = ctypes.c_void_p, ctypes.c_int
+    L.dtc_draft_roi_align_band.argtypes = [p, i, i, p, i, i, i, p, p, i, i, i, i, ctypes.POINTER(ctypes.c_int), p]
+    L.dtc_draft_roi_align_band.restype = i
+    max_items = 4096
+    ws = torch.zeros(16 + 24 * max_items, dtype=torch.uint8, device=dev)
+    out = torch.full_like(ref, -1.0)
+    n_items = ctypes.c_int(0)
+    R = path.B * path.top_n
+
+    def run():
+        return L.dtc_draft_roi_align_band(path.feat_lv, 4, ref.shape[1], path.roi_desc.data_ptr(), R, 7, 7, out.data_ptr(),
+                                          ws.data_ptr(), max_items, a.band_log2, 2, a.rows_cap, ctypes.byref(n_items),
+                                          hip.stream_ptr(dev))
+    rc = run()
+    torch.cuda.synchronize()
+    print("rc", rc, "band items", n_items.value)
+    if rc != 0:
+        return 1
+    n = [int(x) for x in path.n_rois.cpu()]
+    bad = 0
+    for b in range(path.B):
+        g, r = out[b * path.top_n:b * path.top_n + n[b]], ref[b * path.top_n:b * path.top_n + n[b]]
+        bad += int((g != r).any(dim=(1, 2, 3)).sum())
+    print("RoIs that differ from the product kernel: %d of %d" % (bad, sum(n)))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for name, fn in (("band draft (incl. the item kernel + host sync)", run), ("product (cluster kernel)", path._roi_align_box)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        print("%-50s %.4f ms / launch" % (name, e0.elapsed_time(e1) / a.iters))
+    return 0 if bad == 0 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
