@@ -5,8 +5,8 @@ lines.  Models:
   roi             one RoI's window per workgroup (round 1: roi_align_fwd_lds)
   cluster K       K consecutive RoIs of the visiting order merged greedily (roi_align_fwd_tile, merge rule 250 %)
   band H          a workgroup owns a band of H feature rows of one level x a channel block and sweeps it in x with a sliding
-                  LDS window: it stages rows [band start, band end + halo) once per channel, where the halo is what the windows
-                  of the RoIs assigned to the band (by their top row) reach below it
+                  LDS window: it stages the rows its RoIs' windows cover (RoIs are assigned to a band by their CENTRE row, as
+                  in the visiting order: the windows stick out above and below the band) once per channel
 Usage: python tools/r02b/gen_rois.py 4 && python tools/r02b/fill_models.py 4"""
 import sys
 import numpy as np
@@ -57,23 +57,23 @@ def main(n_img):
                     for row in range(y0, y1 + 1):
                         clus[K] += len(lines_of(row, xa0, min(xa1, W - 1), W))
                     k += cnt
-        # band sweeps: RoI -> band of its window's top row; the band stages full-width rows [H*b, max window bottom]
+        # band sweeps: RoI -> band of its window's CENTRE row (what the visiting order of fpn.hip does); the band stages the rows
+        # [min window top, max window bottom] over the x range its windows cover
         for H in bands:
             for lvl, (Hl, Wl) in enumerate(SHAPES):
                 lw = [w for w in wins if w[1] == lvl]
                 if not lw: continue
                 nb = -(-Hl // H)
-                bottom = [-1] * nb
+                top, bottom = [1 << 30] * nb, [-1] * nb
                 xs = [[Wl, -1] for _ in range(nb)]
                 for w in lw:
-                    b = w[4] // H
-                    bottom[b] = max(bottom[b], w[5])
+                    b = min(((w[4] + w[5]) // 2) // H, nb - 1)
+                    top[b] = min(top[b], w[4]); bottom[b] = max(bottom[b], w[5])
                     xs[b][0] = min(xs[b][0], w[2]); xs[b][1] = max(xs[b][1], w[3])
                 for b in range(nb):
                     if bottom[b] < 0: continue
-                    rows = bottom[b] - b * H + 1
-                    band_lds[H] = max(band_lds[H], rows)
-                    for row in range(b * H, bottom[b] + 1):
+                    band_lds[H] = max(band_lds[H], bottom[b] - top[b] + 1)
+                    for row in range(top[b], bottom[b] + 1):
                         bands[H] += len(lines_of(row, xs[b][0], xs[b][1], Wl))
     R = tot["rois"]
     print("%d images, %d RoIs; line fills per (RoI, channel):" % (n_img, R))
@@ -99,10 +99,10 @@ def band_batches(n_img, H=32, Wc=64):
         for lvl, (Hl, Wl) in enumerate(SHAPES):
             lw = [w for w in wins if w[1] == lvl]
             for b in range(-(-Hl // H)):
-                bw = sorted([w for w in lw if w[4] // H == b], key=lambda w: (w[2] + w[3]))
+                bw = sorted([w for w in lw if min(((w[4] + w[5]) // 2) // H, -(-Hl // H) - 1) == b], key=lambda w: (w[2] + w[3]))
                 if not bw: continue
                 per_band.append((lvl, len(bw)))
-                rows_hist.append((lvl, max(w[5] for w in bw) - b * H + 1))
+                rows_hist.append((lvl, max(w[5] for w in bw) - min(w[4] for w in bw) + 1))
                 k = 0
                 while k < len(bw):
                     xa, n = bw[k][2], 0

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(RoiAlignParam
                                                                    int rows_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CG = 4 * NQ;
-  __shared__ int s_next, s_i1, s_xa, s_xb, s_rows;
+  __shared__ int s_next, s_i1, s_xa, s_xb, s_rmin, s_rmax;
   __shared__ int s_wx0[64], s_wx1[64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ncg = ceil_div(p.channels, CG);
@@ -112,15 +112,18 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(RoiAlignParam
   float* out = reinterpret_cast<float*>(p.out);
   const float rpw = __frcp_rn((float)p.pooled_w);
 
-  // ---- rows the band's windows reach: [row0, row0 + rows) --------------------------------------------------------------
-  if (tid == 0) { s_rows = 0; s_next = it.first; }
+  // ---- rows the band's windows reach: [rbase, rbase + rows).  The visiting order bands a RoI by its CENTRE row, so windows
+  // stick out above the band's first row as well as below its last one.
+  if (tid == 0) { s_rmin = 0x7fffffff; s_rmax = -1; s_next = it.first; }
   __syncthreads();
   for (int i = tid; i < it.count; i += kBandThreads) {
-    const RoiHead hd = load_roi_head(p, it.first + i);
-    atomicMax(&s_rows, band_window(p, hd, H, W).y1 - it.row0 + 1);
+    const BandWin w = band_window(p, load_roi_head(p, it.first + i), H, W);
+    atomicMin(&s_rmin, w.y0);
+    atomicMax(&s_rmax, w.y1);
   }
   __syncthreads();
-  const int rows = min(s_rows, rows_cap);           // TODO (2): RoIs whose window leaves the image take the gather path
+  const int rbase = s_rmin;
+  const int rows = min(s_rmax - rbase + 1, rows_cap);   // TODO (2): RoIs whose window leaves the image take the gather path
   int res_a = 0, res_b = 0;                          // columns [res_a, res_b) are resident in the ring (uniform)
   int i0 = it.first;
   const int i_end = it.first + it.count;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(RoiAlignParam
       const int c = e % CG, t = e / CG, gx = t % ngx, row = t / ngx;
       const int col = xa + 4 * gx;
       if (overlap && col >= keep_a && col < keep_b) continue;           // still resident
-      const int frow = min(it.row0 + row, H - 1);
+      const int frow = min(rbase + row, H - 1);
       const float* src = fbase + (int64_t)c * L.stride_c + (int64_t)frow * L.stride_h;
       float v[4];
 #pragma unroll
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(RoiAlignParam
           const AxisEntry ey = make_axis(hd.sh, hd.bin_h, ph, i, 2, H);
           const AxisEntry ex = make_axis(hd.sw, hd.bin_w, pw, i, 2, W);
           yl[i] = ey.l; yh[i] = ey.h; xl[i] = ex.l; xh[i] = ex.h;
-          ylo[i] = min(ey.lo - it.row0, rows - 1) * (kRingCols * 16); yhi[i] = min(ey.hi - it.row0, rows - 1) * (kRingCols * 16);
+          ylo[i] = min(ey.lo - rbase, rows - 1) * (kRingCols * 16); yhi[i] = min(ey.hi - rbase, rows - 1) * (kRingCols * 16);
           xlo[i] = (ex.lo & (kRingCols - 1)) << 4; xhi[i] = (ex.hi & (kRingCols - 1)) << 4;
         }
         bf32x2 acc[NQ][2];
