@@ -5,7 +5,7 @@ the product kernel's bit for bit and times both.
     python tools/r03_draft/run_band.py --build      # here (hipcc cross-compiles); the .so travels to the GPU box with gpurun
     python tools/r03_draft/run_band.py              # on the GPU box
 
-The RoIs of levels the draft is not meant for can be masked out with --level (default: all levels)."""
+Mismatches are reported per FPN level (the draft clamps bands deeper than --rows-cap rows: TODO (2) in the kernel file)."""
 import argparse
 import ctypes
 import os
@@ -65,11 +65,17 @@ def main():
     if rc != 0:
         return 1
     n = [int(x) for x in path.n_rois.cpu()]
-    bad = 0
+    bad, per_level = 0, {}
     for b in range(path.B):
         g, r = out[b * path.top_n:b * path.top_n + n[b]], ref[b * path.top_n:b * path.top_n + n[b]]
-        bad += int((g != r).any(dim=(1, 2, 3)).sum())
-    print("RoIs that differ from the product kernel: %d of %d" % (bad, sum(n)))
+        diff = (g != r).any(dim=(1, 2, 3)).cpu()
+        lv = path.roi_levels[b, :n[b]].cpu()
+        for l in range(4):
+            tot, d = per_level.get(l, (0, 0))
+            per_level[l] = (tot + int((lv == l).sum()), d + int((diff & (lv == l)).sum()))
+        bad += int(diff.sum())
+    # (P3-P5 bands whose windows cover more rows than --rows-cap are expected to differ until TODO (2) of the draft is done)
+    print("RoIs that differ from the product kernel: %d of %d; per level (RoIs, differing): %s" % (bad, sum(n), per_level))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for name, fn in (("band draft (incl. the item kernel + host sync)", run), ("product (cluster kernel)", path._roi_align_box)):
         for _ in range(3):
