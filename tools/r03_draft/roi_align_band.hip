@@ -28,7 +28,8 @@
 // LDS image holds (rare: a tall P2 box at the top of a band) must hand those RoIs to the per-output gather; (3) per-RoI axis
 // tables from a prep kernel instead of 4 x make_axis per lane and channel group; (4) channel-group-major dispatch + XCD
 // slices; (5) the pad-slot trick of the cluster kernel against the transposing-commit bank conflicts; (6) fp16 / bf16 inputs;
-// (7) 16-byte buffer loads + a register pipeline for the staging (scalar loads here); (8) registers: at the 128-VGPR cap of a
+// (7) raw buffer loads issued under the pooling of the previous batch (here: 16-byte global loads, four per thread in flight,
+// between the two barriers); (8) registers: at the 128-VGPR cap of a
 // 1024-thread workgroup this draft spills 92 bytes per lane (-Rpass-analysis=kernel-resource-usage) -- the four make_axis results
 // per lane live across the quad loop; tables (3) remove them.
 #include <string.h>
@@ -148,23 +149,49 @@ __global__ __launch_bounds__(kBandThreads) void roi_align_fwd_band(RoiAlignParam
     }
     __syncthreads();
     const int i1 = band_uni(s_i1), xa = band_uni(s_xa), xb = min(band_uni(s_xb), (W - 1) | 3);
-    // ---- load the columns of [xa, xb] the ring does not hold: 4-pixel pieces (row, group, channel), transposed into LDS ---
-    // resident and required intervals are multiples of 4 columns; what stays is their intersection
+    // ---- load the columns of [xa, xb] the ring does not hold: 4-pixel pieces, transposed into LDS ---------------------------
+    // resident and required intervals are multiples of 4 columns; what stays is their intersection, what is loaded is the
+    // (at most two) column runs left and right of it: gA + gB groups of 4 columns
     const int keep_a = max(xa, res_a), keep_b = min(xb + 1, res_b);
     const bool overlap = keep_b > keep_a;
     const int ngx = (xb + 1 - xa) >> 2;
-    const int npiece = rows * ngx * CG;
-    for (int e = tid; e < npiece; e += kBandThreads) {
-      const int c = e % CG, t = e / CG, gx = t % ngx, row = t / ngx;
-      const int col = xa + 4 * gx;
-      if (overlap && col >= keep_a && col < keep_b) continue;           // still resident
-      const int frow = min(rbase + row, H - 1);
-      const float* src = fbase + (int64_t)c * L.stride_c + (int64_t)frow * L.stride_h;
-      float v[4];
+    const int gA = overlap ? (keep_a - xa) >> 2 : ngx, gB = overlap ? (xb + 1 - keep_b) >> 2 : 0;
+    const int ng_new = gA + gB;
+    const bool vec = L.stride_w == 1 && (W & 3) == 0 && ((L.stride_h | L.stride_c | L.stride_n) & 3) == 0 &&
+                     (reinterpret_cast<uintptr_t>(L.data) & 15) == 0;
+    if (ng_new > 0) {
+      // a wave-level unit = (channel quad, row, 16 consecutive groups): lane = (channel of the quad, group) -> the 64 loads of a
+      // unit are four 256-byte runs; SU units of a wave are in flight together
+      constexpr int SU = 4;
+      const int n16 = (ng_new + 15) >> 4;
+      const int units = NQ * rows * n16;
+      const int gl = lane & 15, cl = lane >> 4;
+      for (int u0 = wv; u0 < units; u0 += SU * kBandWaves) {
+        float4 v[SU];
+        int dsto[SU];
 #pragma unroll
-      for (int k = 0; k < 4; k++) v[k] = src[(int64_t)min(col + k, W - 1) * L.stride_w];     // draft: scalar loads
-      float* d = reinterpret_cast<float*>(ring + (c >> 2) * plane_bytes) + ((size_t)row * kRingCols + (col & (kRingCols - 1))) * 4 + (c & 3);
-      d[0] = v[0]; d[4] = v[1]; d[8] = v[2]; d[12] = v[3];
+        for (int k = 0; k < SU; k++) {
+          const int u = min(u0 + k * kBandWaves, units - 1);
+          const int g16 = u % n16, t = u / n16, row = t % rows, cq = t / rows;
+          const int g = min(g16 * 16 + gl, ng_new - 1);                  // lanes past the run repeat its last group
+          const int col = g < gA ? xa + 4 * g : keep_b + 4 * (g - gA);
+          const int frow = min(rbase + row, H - 1);
+          const float* src = fbase + (int64_t)(4 * cq + cl) * L.stride_c + (int64_t)frow * L.stride_h;
+          if (vec) v[k] = *reinterpret_cast<const float4*>(src + col);
+          else {
+            v[k].x = src[(int64_t)min(col, W - 1) * L.stride_w]; v[k].y = src[(int64_t)min(col + 1, W - 1) * L.stride_w];
+            v[k].z = src[(int64_t)min(col + 2, W - 1) * L.stride_w]; v[k].w = src[(int64_t)min(col + 3, W - 1) * L.stride_w];
+          }
+          dsto[k] = cq * plane_bytes + (row * kRingCols + (col & (kRingCols - 1))) * 16 + cl * 4;
+        }
+#pragma unroll
+        for (int k = 0; k < SU; k++) {
+          if (u0 + k * kBandWaves < units) {                             // (duplicates of the last group rewrite the same words)
+            float* d = reinterpret_cast<float*>(ring + dsto[k]);
+            d[0] = v[k].x; d[4] = v[k].y; d[8] = v[k].z; d[12] = v[k].w;
+          }
+        }
+      }
     }
     res_a = xa; res_b = xb + 1;
     if (tid == 0) s_next = i0;
