@@ -117,4 +117,11 @@ int launch_roi_align_tile(const RoiAlignParams& p, int in_dtype, int out_dtype, 
 bool roi_align_map_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
 int launch_roi_align_map(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream);
 
+// launchers of the band-sweep kernel (roi_align_band.hip): packed descriptors, sampling_ratio 2, <= 8 x 8 bins, fp32 NCHW maps.
+// Needs a caller-owned workspace (per-RoI axis records + band items).
+constexpr int kVisitBandLog2Sweep = 5;     // band height (log2 feature rows) of the visiting order the sweep is built for
+bool roi_align_band_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
+size_t roi_align_band_workspace_bytes(int n_rois);
+int launch_roi_align_band(const RoiAlignParams& p, int in_dtype, int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 }  // namespace dtc
