@@ -87,6 +87,12 @@ __global__ __launch_bounds__(kRleThreads) void mask_rle_kernel(RleParams p) {
   uint32_t* cnt = p.counts + di * p.runs_stride;
   uint8_t* str = p.str + di * p.str_stride;
   const long long npx = (long long)cw * ch;
+  // dtc_mask_paste skips a crop that does not fit image b's region (offset + area > capacity) but still publishes its offset:
+  // encoding from there would read stale bytes, the next image's crops, or past the buffer.  Report "no valid data".
+  if (p.offsets[di] < 0 || p.offsets[di] + npx > p.cap) {
+    if (tid == 0) { p.n_runs[di] = -1; p.str_len[di] = -1; }
+    return;
+  }
   const bool full_h = (y0 == 0 && y1 == im_h);      // crop columns are contiguous in the frame sequence
   if (tid == 0) running = 0;
   __syncthreads();

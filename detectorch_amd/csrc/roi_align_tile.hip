@@ -9,20 +9,26 @@
 // RoI-stationary workgroup (roi_align_fwd_lds in roi_align.hip) spends 16.5 fills per (RoI, channel) where 2.2 are
 // compulsory -- measured 52 M fills / 0.52 ms per 8000-RoI launch, with every staging variant (round 1).
 // RoIs that are neighbours in the visiting order of dtc_fpn_collect_distribute (level, row band, x) overlap about two-fold
-// and sit side by side, so here a workgroup owns K consecutive RoIs of that order:
-//   1. their windows are merged greedily into clusters while the merge does not ADD lines (rows x (bytes + 128)) and the
-//      union fits the LDS window -- a cluster's rows are 150-250 B wide instead of 48 B, i.e. every fetched line is mostly used;
-//   2. the cluster's union window is staged ONCE per channel quad with 16-byte row-piece loads (4 pixels of one channel),
-//      issue-early / write-late through registers, into an LDS image [quad][pixel][4 channels];
+// and sit side by side, so here a workgroup owns K consecutive RoIs of that order (K = 256 threads / bins):
+//   1. their windows are merged greedily into clusters while the union window stays a compact patch -- at most merge_pct
+//      (250) % of the pixels the members would stage one by one (the AREA rule, :tile kernel phase B) -- and fits the LDS
+//      image and the register pipeline; a cluster's rows are 150-250 B wide instead of 48 B: every fetched line is mostly used;
+//   2. the cluster's union window is staged ONCE per channel quad with 16-byte row-piece loads (4 pixels of one channel; raw
+//      buffer loads, issued before the previous pass is pooled and committed after it), into an LDS image [quad][pixel][4 channels];
 //   3. lane <-> (RoI, bin): sampling positions and weights are formed ONCE per lane (registers), then every channel quad
-//      costs 16 ds_read_b128 + the reference's multiply-adds, and the four results go straight to the [R,C,PH,PW] output
-//      (lanes of consecutive bins -> 196-byte runs; no LDS transposition slab, no table lookups in the loop).
+//      costs 16 ds_read_b128 + the reference's multiply-adds (packed fp32, the reference's order);
+//   4. the results of a pass go to an LDS slab [RoI][channel][bin] -- contiguous per RoI exactly like the [R,C,PH,PW] output --
+//      that leaves as 16-byte stores while the next pass is being committed (direct 4-byte stores from the pooling lanes cost
+//      0.135 ms of a 0.61 ms launch).
 // The LDS image is padded by one pixel slot every 8 pixels (phys = px + px/8): the transposing ds_write_b32 of 16
 // consecutive 4-pixel groups x 2 channels then spread over all 32 banks two-way (free for ds_write_b32) instead of eight-way.
 //
+// Since round 3 the FPN box head (7x7 bins, fp32 maps) is pooled by the band-sweep kernel (roi_align_band.hip); this kernel
+// serves the mask head (14x14 bins), 16-bit feature maps, and the entries without a workspace.
+//
 // Anything the cluster path does not cover takes a correct slow path inside the same kernel: levels whose rows are not
-// 16-byte aligned (P5: 42 columns) are staged with clamped scalar loads; a single RoI whose window exceeds the LDS image
-// is gathered per output straight from global memory; padding rows (level < 0) are zero-filled.
+// 16-byte aligned (P5: 42 columns) are staged with unaligned pieces or clamped scalar loads; a single RoI whose window exceeds
+// the LDS image is gathered per output straight from global memory; padding rows (level < 0) are zero-filled.
 #include <stdlib.h>
 
 #include <mutex>
@@ -34,14 +40,12 @@ namespace dtc {
 constexpr int kTileMaxK = 32;                       // RoIs per workgroup (upper bound of the K the host picks)
 constexpr int kTileRoiBytes = 48, kTileGroupBytes = 32;
 constexpr int kTileHdrBytes = kTileMaxK * (kTileRoiBytes + kTileGroupBytes) + 16;
-// Workgroup shapes (threads, 16-byte row pieces a thread carries per pass, waves per SIMD the register budget allows):
+// Workgroup shape (threads, 16-byte row pieces a thread carries per pass, waves per SIMD the register budget allows):
 //   256 threads x 8 pieces, 3 workgroups / CU (<= 168 VGPRs, 52 KB LDS each)   K = 5 RoIs of 7x7 bins per workgroup
-//   512 threads x 4 pieces, 2 workgroups / CU (<= 128 VGPRs, 78 KB)            K = 10
-//  1024 threads x 4 pieces, 1 workgroup  / CU (<= 128 VGPRs, 156 KB)           K = 20
+// (512- and 1024-thread shapes -- K = 10 / 20 -- were built and measured in round 2: bit-exact, slower (0.42 / 0.54 ms against
+// 0.37), and spilling; removed in round 3, `git show 1687f14:detectorch_amd/csrc/roi_align_tile.hip`.)
 template <int NT> struct TileShape;
 template <> struct TileShape<256> { static constexpr int kUnits = 8, kWaves = 3, kLdsKB = 52; };
-template <> struct TileShape<512> { static constexpr int kUnits = 4, kWaves = 4, kLdsKB = 78; };
-template <> struct TileShape<1024> { static constexpr int kUnits = 4, kWaves = 4, kLdsKB = 156; };
 
 struct TileRoi {                        // 48 bytes
   int lvl, b, x0, x1, y0, y1, r, valid;   // window in feature pixels of its level, inclusive
@@ -524,7 +528,7 @@ namespace dtc {
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
 struct TileConfig {
-  int nt = 256;        // threads per workgroup: 256 | 512 | 1024
+  int nt = 256;        // threads per workgroup
   int lds_kb = 0;      // LDS per workgroup (0: TileShape<NT>::kLdsKB)
   int k = 0;           // RoIs per workgroup (0: threads / bins)
   int ch_block = 0;    // channels per workgroup (0: chosen per launch)
@@ -535,7 +539,6 @@ struct TileConfig {
 static const TileConfig& tile_config() {   // development knobs, resolved ONCE (thread-safe static initialisation)
   static const TileConfig cfg = [] {
     TileConfig c;
-    if (const char* e = getenv("DTC_RA_TILE_NT")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) c.nt = v; }
     if (const char* e = getenv("DTC_RA_TILE_LDS_KB")) { const int v = atoi(e); if (v >= 8 && v <= 160) c.lds_kb = v; }
     if (const char* e = getenv("DTC_RA_TILE_K")) { const int v = atoi(e); if (v >= 1 && v <= kTileMaxK) c.k = v; }
     if (const char* e = getenv("DTC_RA_TILE_MERGE")) { const int v = atoi(e); if (v >= 100 && v <= 100000) c.merge_pct = v; }
@@ -580,11 +583,7 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
 
 template <typename TIn, typename TOut>
 static int launch_tile_t(const RoiAlignParams& p, hipStream_t stream) {
-  switch (tile_config().nt) {
-    case 512: return launch_tile_nt<TIn, TOut, 512>(p, stream);
-    case 1024: return launch_tile_nt<TIn, TOut, 1024>(p, stream);
-    default: return launch_tile_nt<TIn, TOut, 256>(p, stream);
-  }
+  return launch_tile_nt<TIn, TOut, 256>(p, stream);
 }
 
 bool roi_align_tile_supported(const RoiAlignParams& p, int in_dtype, int out_dtype) {

@@ -218,7 +218,11 @@ def assemble_results(dets, det_count, im_sizes=None, rle_str=None, rle_len=None,
                 segs = []
                 for k in sel:
                     if rle_len[i, k] < 0:
-                        raise RuntimeError("device RLE buffer too small for image %d detection %d" % (first_image + i, k))
+                        raise RuntimeError("device RLE buffer too small (or mask crop capacity exceeded) for image %d "
+                                           "detection %d" % (first_image + i, k))
+                    if rle_len[i, k] > rle_str.shape[2]:     # a gatherer that ships fewer bytes than the device stride
+                        raise RuntimeError("RLE string of image %d detection %d was truncated in transit (%d > %d bytes)"
+                                           % (first_image + i, k, rle_len[i, k], rle_str.shape[2]))
                     segs.append({'size': [h, w], 'counts': rle_str[i, k, :rle_len[i, k]].tobytes().decode('ascii')})
                 all_segms[j][first_image + i] = segs
     return all_boxes, all_segms

@@ -243,7 +243,8 @@ int dtc_mask_paste(const float* masks, const int32_t* mask_index, int n_cls, int
  *   rle_counts uint32 [B,max_out,runs_stride]  run lengths (column-major, first run = zeros), rle_n_runs int32 [B,max_out]
  *   rle_str    uint8  [B,max_out,str_stride]   the compressed "counts" string (ASCII, no terminator), rle_str_len int32
  * A detection whose runs (string) do not fit gets rle_n_runs = -(runs needed) (rle_str_len = -(bytes needed)) and no
- * valid data: re-run with larger strides or encode that one on the host.  d >= det_count[b]: 0 / 0. */
+ * valid data: re-run with larger strides or encode that one on the host.  A detection whose crop did not fit
+ * per_image_capacity (dtc_mask_paste skipped it: mask_bytes[b] > capacity) gets -1 / -1.  d >= det_count[b]: 0 / 0. */
 int dtc_mask_rle(const uint8_t* crops, long long per_image_capacity, const int32_t* mask_rects,
                  const long long* mask_offsets, const int32_t* det_count, const float* im_size, int batch, int max_out,
                  uint32_t* rle_counts, int runs_stride, int32_t* rle_n_runs, uint8_t* rle_str, int str_stride,

@@ -57,6 +57,44 @@ def test_cfg5_shape_2000_proposals_fp16_features(oracle):
     assert np.array_equal(path.dets[0, :D].cpu().numpy(), ref["dets"][:D])
 
 
+def test_cfg5_real_shape_batch8_c256_fp16(oracle):
+    """BASELINE cfg5 at its REAL shape (round-2 VERDICT: only C = 8, B = 1 was tested): B = 8 images x 2000 RoIs, C = 256, fp16
+    feature maps, hipGraph replay.  That is the 16 000-RoI launch of the cluster-stationary kernel with 128-channel blocks
+    (roi_align_tile.hip: ngrp * ceil(C / 128) >= 6144).  Image 0 against the oracle chain on the up-cast maps: proposals,
+    levels and detections exact, fp16 pooled features to rel 1e-3; and the same launch with FLOAT32 output bit-equal."""
+    import chain
+    from detectorch_amd import hip
+    from detectorch_amd.pipeline import FpnRegionPath, synthetic_batch
+    dev = torch.device("cuda", 0)
+    B, C, T = 8, 256, 2000
+    path = FpnRegionPath(B, dev, channels=C, collect_top_n=T, feat_dtype=torch.float16)
+    inputs = synthetic_batch(B, dev, seed=5000, channels=C, top_n=T, feat_dtype=torch.float16)
+    path.bind(*inputs)
+    path.step(use_graph=True)
+    path.step(use_graph=True)
+    torch.cuda.synchronize()
+    rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, sf, im_size = inputs
+    host = lambda t: t.float().cpu().numpy()
+    b = 0
+    ref = chain.fpn_hot_path([host(c[b]) for c in rpn_cls], [host(d[b]) for d in rpn_bbox], [host(f[b:b + 1]) for f in feats],
+                             host(cls_score[b]), host(bbox_pred[b]), host(masks[b * path.max_out:(b + 1) * path.max_out]),
+                             float(sf[b]), host(im_size[b]), path.pad_h, path.pad_w, top_n=T)
+    n = int(path.n_rois[b])
+    assert n == ref["rois"].shape[0] and n > 1000
+    assert np.array_equal(path.rois5[b, :n, 1:].cpu().numpy(), ref["rois"])
+    assert np.array_equal(path.roi_levels[b, :n].cpu().numpy(), ref["roi_levels"])
+    assert np.allclose(path.box_feats[:n].float().cpu().numpy(), ref["box_feats"], rtol=1e-3, atol=1e-3)
+    D = min(int(path.det_count[b]), path.max_out)
+    assert np.array_equal(path.dets[b, :D].cpu().numpy(), ref["dets"][:D])
+    # fp32 output of the SAME 16 000-descriptor launch (fp16 maps, fp32 accumulate, no final rounding): bit-equal
+    out32 = torch.empty((B * T, C, 7, 7), dtype=torch.float32, device=dev)
+    hip.check(hip.lib().dtc_roi_align_forward_packed(path.feat_lv, 4, C, hip.DTC_F16, path.roi_desc.data_ptr(), B * T, 7, 7, 2,
+                                                     out32.data_ptr(), hip.DTC_F32, hip.stream_ptr(dev)), "packed fp16->fp32")
+    torch.cuda.synchronize()
+    assert np.array_equal(out32[:n].cpu().numpy(), ref["box_feats"])
+    assert torch.equal(out32.to(torch.float16), path.box_feats)       # every image: the fp16 output is that, rounded once
+
+
 def test_overlapped_split_equals_single(oracle):
     """Two sub-batches on two streams inside one hipGraph give exactly the single-stream result."""
     from detectorch_amd.pipeline import FpnRegionPath, OverlappedRegionPath, synthetic_batch
@@ -149,3 +187,25 @@ def test_c4_region_path_vs_oracle_chain(oracle):
                                     path.im_h, path.im_w, pooled=pooled)
             assert chain.compare_c4_with_gpu(path, b, ref)
             assert ref["rois"].shape[0] == 1000 and ref["dets"].shape[0] >= 100
+
+
+@pytest.mark.parametrize("pooled", [7, 14])
+def test_c4_region_path_true_channel_count(oracle, pooled):
+    """BASELINE cfg2 at its REAL channel count (round-2 VERDICT: the C4RegionPath test ran C = 32): res4 [1,1024,50,84], 1000
+    proposals, adaptive sampling, 7x7 (as cfg2 names it) and 14x14 (the reference's default): the whole chain for one image,
+    every intermediate bit-exact (the map-stationary kernel's 128 channel-group workgroups all included)."""
+    import chain
+    from detectorch_amd.pipeline import C4RegionPath, synthetic_c4_batch
+    dev = torch.device("cuda", 0)
+    B, C = 1, 1024
+    path = C4RegionPath(B, dev, channels=C, pooled=pooled)
+    inputs = synthetic_c4_batch(B, dev, seed=2100, channels=C)
+    path.bind(*inputs)
+    path.step(use_graph=True)
+    path.step(use_graph=True)
+    torch.cuda.synchronize()
+    rpn_cls, rpn_bbox, feat, cls_score, bbox_pred, sf, im_size = [x.cpu().numpy() for x in inputs]
+    ref = chain.c4_hot_path(rpn_cls[0], rpn_bbox[0], feat[0:1], cls_score[0], bbox_pred[0], sf[0], im_size[0], path.im_h,
+                            path.im_w, pooled=pooled)
+    assert chain.compare_c4_with_gpu(path, 0, ref)
+    assert ref["rois"].shape[0] == 1000

@@ -41,7 +41,7 @@ def main():
         bad += int((band != ref).any(dim=(1, 2, 3)).sum())
     ctl = paths[0].band_ws[:256].cpu().numpy().view(np.int32)
     print("%s RoIs differing from the cluster kernel: %d of %d ; band items %d gather items %d ; slices %s"
-          % (a.tag, bad, 2 * R, ctl[0], ctl[1], list(ctl[24:33])))
+          % (a.tag, bad, 2 * R, ctl[0], ctl[1], [int(x) for x in ctl[24:33]]))
 
     def t(fn):
         for _ in range(3):
@@ -63,6 +63,17 @@ def main():
         L.dtc_roi_align_forward_packed(p.feat_lv, 4, p.C, p.feat_code, p.roi_desc.data_ptr(), R, 7, 7, 2, p.box_feats.data_ptr(),
                                        p.out_code, hip.stream_ptr(dev))
     tb, tc = t(band), t(cluster)
+    if hasattr(L, "dtc_debug_band_trace"):          # the development build (tools/r03/build_trace_lib.sh): cycles per phase
+        buf = (ctypes.c_ulonglong * 16)()
+        L.dtc_debug_band_trace(buf, 1)
+        band(0)
+        torch.cuda.synchronize()
+        L.dtc_debug_band_trace(buf, 1)
+        names = ["unit fetch", "first batch (issue+commit)", "set-up", "issue", "pool", "wait B1", "commit", "slab store", "wait B2"]
+        tot = float(sum(buf[:9])) or 1.0
+        print("phase trace of one launch (thread 0 of every workgroup, shader cycles summed over %d workgroups): total %.1f M" % (256, tot / 1e6))
+        for i, nm in enumerate(names):
+            print("   %-28s %8.2f M  %5.1f %%" % (nm, buf[i] / 1e6, 100.0 * buf[i] / tot))
     alg = paths[0].box_roialign_bytes()
     print("%s band entry (prep kernels + sweep) %.4f ms = %.2f TB/s (frac %.3f) | cluster kernel %.4f ms (frac %.3f) | env %s"
           % (a.tag, tb, alg / tb / 1e9, alg / tb / 1e9 / 8.0, tc, alg / tc / 1e9 / 8.0,
