@@ -663,7 +663,7 @@ namespace dtc {
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 struct BandConfig {
-  int enabled = 1;
+  int enabled = 0;     // DTC_RA_BAND=1: the workspace entry takes the band sweep (experimental; default: prepared cluster kernel)
   int rows_cap = 0;    // 0: what the LDS holds next to the slab
   int kmax = 0;        // RoIs per batch (0: threads / bins, at most 20)
   int grid = 0;        // workgroups (0: one per CU)
@@ -788,7 +788,12 @@ size_t roi_align_band_workspace_bytes(int n_rois) { return band_ws_bytes(n_rois)
 }  // namespace dtc
 
 // ---- C ABI ----------------------------------------------------------------------------------------------------------------------
-DTC_API size_t dtc_roi_align_band_workspace_bytes(int n_rois) { return dtc::roi_align_band_workspace_bytes(n_rois); }
+DTC_API size_t dtc_roi_align_band_workspace_bytes(int n_rois) {
+  // enough for either kernel the entry may take, at the two pooled sizes of the FPN heads
+  const size_t a = dtc::roi_align_band_workspace_bytes(n_rois);
+  const size_t b = dtc::roi_align_tile_workspace_bytes(n_rois, 7, 7), c = dtc::roi_align_tile_workspace_bytes(n_rois, 14, 14);
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
+}
 
 DTC_API int dtc_roi_align_forward_banded(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,
                                          const float* roi_desc, int n_rois, int pooled_h, int pooled_w, int sampling_ratio,
@@ -806,6 +811,15 @@ DTC_API int dtc_roi_align_forward_banded(const dtc_feat_level* levels, int n_lev
   p.pooled_h = pooled_h; p.pooled_w = pooled_w; p.sampling_ratio = sampling_ratio;
   if (workspace && dtc::roi_align_band_supported(p, in_dtype, out_dtype))
     return dtc::launch_roi_align_band(p, in_dtype, out_dtype, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+  // the cluster-stationary kernel with its per-launch preparation pass: small channel blocks in channel-major order
+  static const bool no_prep = [] { const char* e = getenv("DTC_RA_TILE_PREP"); return e && atoi(e) == 0; }();
+  bool all_nhwc = channels > 1;
+  for (int i = 0; i < n_levels; i++) all_nhwc = all_nhwc && levels[i].stride_c == 1;
+  if (workspace && !no_prep && !all_nhwc && (channels & 3) == 0 && pooled_h <= 16 && pooled_w <= 16 &&
+      workspace_bytes >= dtc::roi_align_tile_workspace_bytes(n_rois, pooled_h, pooled_w) && dtc::roi_align_tile_supported(p, in_dtype, out_dtype)) {
+    p.xcd_remap = 1;
+    return dtc::launch_roi_align_tile_prepared(p, in_dtype, out_dtype, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+  }
   // anything the sweep does not cover (other sampling ratios / bin counts / dtypes, channels_last maps): the packed entry
   return dtc_roi_align_forward_packed(levels, n_levels, channels, in_dtype, roi_desc, n_rois, pooled_h, pooled_w, sampling_ratio,
                                       out, out_dtype, stream);

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--mask", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     paths = []
@@ -63,6 +64,18 @@ def main():
         L.dtc_roi_align_forward_packed(p.feat_lv, 4, p.C, p.feat_code, p.roi_desc.data_ptr(), R, 7, 7, 2, p.box_feats.data_ptr(),
                                        p.out_code, hip.stream_ptr(dev))
     tb, tc = t(band), t(cluster)
+    if a.mask:
+        Rm = a.batch * paths[0].max_out
+        def mask_ws(i):
+            p = paths[i]
+            L.dtc_roi_align_forward_banded(p.feat_lv, 4, p.C, p.feat_code, p.m_desc.data_ptr(), Rm, 14, 14, 2, p.mask_feats.data_ptr(),
+                                           p.out_code, p.band_ws.data_ptr(), p.band_ws.numel(), hip.stream_ptr(dev))
+        def mask_packed(i):
+            p = paths[i]
+            L.dtc_roi_align_forward_packed(p.feat_lv, 4, p.C, p.feat_code, p.m_desc.data_ptr(), Rm, 14, 14, 2, p.mask_feats.data_ptr(),
+                                           p.out_code, hip.stream_ptr(dev))
+        ref = paths[0].mask_feats.clone(); mask_ws(0); torch.cuda.synchronize()
+        print("%s mask head: workspace entry == packed entry: %s ; %.4f ms vs %.4f ms" % (a.tag, bool(torch.equal(ref, paths[0].mask_feats)), t(mask_ws), t(mask_packed)))
     if hasattr(L, "dtc_debug_band_trace"):          # the development build (tools/r03/build_trace_lib.sh): cycles per phase
         buf = (ctypes.c_ulonglong * 16)()
         L.dtc_debug_band_trace(buf, 1)
