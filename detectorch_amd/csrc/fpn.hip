@@ -10,7 +10,7 @@
 
 #include <mutex>
 
-#include "roi_align_common.h"
+#include "dtc_common.h"
 
 namespace dtc {
 DTC_PT_TABLE(fpn)
@@ -483,12 +483,10 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
   p.in_boxes = in_boxes; p.in_scores = in_scores; p.in_counts = in_counts; p.L_in = n_in_levels; p.P = in_stride;
   p.top_n = post_nms_top_n; p.k_min = k_min; p.k_max = k_max; p.inputs_sorted = inputs_sorted; p.rois5 = rois5; p.roi_scores = roi_scores;
   p.roi_levels = roi_levels; p.n_out = n_out; p.rois_by_level = rois_by_level; p.level_counts = level_counts;
-  // visiting-order band height (log2 feature rows).  The scored call is the box head, whose RoIAlign is the band-sweep kernel
-  // (roi_align_band.hip): it wants the 32-row bands it is built for.  The unscored call is the mask branch, pooled by the
-  // cluster-stationary kernel: 16 rows (clusters stay ~28 rows x 32 pixels; measured 8 rows 0.48, 16 rows 0.41, 32 rows 0.43 ms
-  // per 8000-RoI launch of that kernel).  DTC_FPN_BAND_LOG2 overrides both (A/B knob).
-  static const int band_env = [] { const char* e = getenv("DTC_FPN_BAND_LOG2"); const int v = e ? atoi(e) : -1; return v < 0 || v > 8 ? -1 : v; }();
-  p.band_log2 = band_env >= 0 ? band_env : (in_scores ? dtc::kVisitBandLog2Sweep : 4);
+  // visiting-order band height (log2 feature rows): 16 rows suits the cluster-stationary RoIAlign kernel (clusters of ~5
+  // neighbours stay ~28 rows x 32 pixels; measured 8 rows 0.48, 16 rows 0.41, 32 rows 0.43 ms per 8000-RoI box-head launch)
+  static const int band_log2 = [] { const char* e = getenv("DTC_FPN_BAND_LOG2"); const int v = e ? atoi(e) : 4; return v < 0 || v > 8 ? 4 : v; }();
+  p.band_log2 = band_log2;
   p.idx_restore = idx_restore; p.roi_order = roi_order; p.roi_desc = roi_order ? roi_desc : nullptr;
   size_t smem = in_scores ? (size_t)dtc::next_pow2((int)n_max) * sizeof(uint64_t) : 16;
   if (in_scores && inputs_sorted) smem = (size_t)post_nms_top_n * sizeof(uint64_t) + (size_t)n_max * sizeof(float) + 16;

@@ -18,10 +18,6 @@ struct RoiAlignParams {
   int ch_block;   // channels per workgroup of the LDS kernel (multiple of 64): setup (tables, window) is paid once per block
   int cts64;      // 1: allow 64-channel sub-tiles (one bin per ds_read_b128 lane group: conflict-free taps)
   int xcd_remap;  // 1: workgroup -> work-item mapping keeps each XCD on a contiguous range of the visiting order
-  // cluster-stationary kernel only: what tile_prep_kernel formed once per launch (per-RoI windows + axis samples, per-group
-  // clusters), so that a workgroup's set-up is a few loads whatever its channel block (nullptr: formed in the workgroup)
-  const void* prep_rois = nullptr;
-  const void* prep_groups = nullptr;
 };
 
 // XCD-aware work assignment.  The dispatcher deals workgroups round-robin over the 8 XCDs (workgroup b runs on XCD b % 8)
@@ -117,18 +113,8 @@ __device__ __forceinline__ RoiHead load_roi_head(const RoiAlignParams& p, int ri
 // launchers of the cluster-stationary kernel (roi_align_tile.hip); in_dtype / out_dtype are DTC_* codes
 bool roi_align_tile_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
 int launch_roi_align_tile(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream);
-// same kernel with the per-launch preparation pass (needs a caller-owned workspace): small channel blocks in channel-major order
-size_t roi_align_tile_workspace_bytes(int n_rois, int pooled_h, int pooled_w);
-int launch_roi_align_tile_prepared(const RoiAlignParams& p, int in_dtype, int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream);
 // launchers of the map-stationary kernel (roi_align_map.hip): single-level inputs whose whole map fits LDS
 bool roi_align_map_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
 int launch_roi_align_map(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream);
-
-// launchers of the band-sweep kernel (roi_align_band.hip): packed descriptors, sampling_ratio 2, <= 8 x 8 bins, fp32 NCHW maps.
-// Needs a caller-owned workspace (per-RoI axis records + band items).
-constexpr int kVisitBandLog2Sweep = 5;     // band height (log2 feature rows) of the visiting order the sweep is built for
-bool roi_align_band_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
-size_t roi_align_band_workspace_bytes(int n_rois);
-int launch_roi_align_band(const RoiAlignParams& p, int in_dtype, int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace dtc

@@ -314,78 +314,6 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
   TT_MARK(10);
 }
 
-// One axis sample / the per-launch preparation records (tile_prep_kernel): what the workgroups of ALL channel blocks of a group
-// of K RoIs would otherwise each re-derive.
-constexpr int kTilePrepAxis = 32;                         // 2 samples x pooled size <= 32 per axis
-struct TilePrepRoi { TileRoi t; AxisEntry y[kTilePrepAxis]; AxisEntry x[kTilePrepAxis]; };      // 48 + 2 x 512 B
-struct TilePrepGroup { int ng, pad[3]; TileGroup g[kTileMaxK]; };                               // 16 + 32 x 32 B
-static_assert(sizeof(AxisEntry) == 16 && sizeof(TilePrepRoi) == 48 + 1024 && sizeof(TilePrepGroup) == 16 + 1024, "prep record layout");
-
-// Phases A + B of a group of K RoIs, by one whole wavefront.  A: lane k forms the window of RoI grp * K + k (returned in t).
-// B: greedy clustering along the visiting order on the register copies (readlane with a uniform index: no LDS round trips, no
-// barrier between A and B); every lane walks the same clusters, emit(i, cluster i) is called for each; returns their number.
-template <int NT, typename Emit>
-__device__ __forceinline__ int tile_windows_and_clusters(const RoiAlignParams& p, int grp, int K, int bins, int win_bytes,
-                                                         int merge_pct, int lane, TileRoi& t, Emit emit) {
-  constexpr int kMaxPos = TileShape<NT>::kUnits * (NT / 64) * 16;          // 16-byte pieces the register pipeline can carry per quad
-  t.lvl = -1; t.b = 0; t.x0 = t.x1 = t.y0 = t.y1 = 0; t.r = 0; t.valid = 0; t.sh = t.sw = 0.f; t.bin_h = t.bin_w = 1.f;
-  const int ri = grp * K + lane;
-  if (lane < K && ri < p.n_rois) {
-    const RoiHead hd = load_roi_head(p, ri);
-    t.valid = 1; t.r = hd.r; t.b = hd.b; t.sh = hd.sh; t.sw = hd.sw; t.bin_h = hd.bin_h; t.bin_w = hd.bin_w;
-    if (hd.lvl >= 0 && hd.lvl < p.n_levels) {
-      t.lvl = hd.lvl;
-      const int H = p.lv[hd.lvl].height, W = p.lv[hd.lvl].width;
-      // sample positions are non-decreasing in (bin, sample): first .lo / last .hi bound the window (roi_align_cpu_loop.cpp:38-90)
-      t.y0 = make_axis(hd.sh, hd.bin_h, 0, 0, 2, H).lo;
-      t.y1 = make_axis(hd.sh, hd.bin_h, p.pooled_h - 1, 1, 2, H).hi;
-      t.x0 = make_axis(hd.sw, hd.bin_w, 0, 0, 2, W).lo;
-      t.x1 = make_axis(hd.sw, hd.bin_w, p.pooled_w - 1, 1, 2, W).hi;
-    }
-  }
-  auto bc = [](int v, int k) { return __builtin_amdgcn_readlane(v, k); };     // k: uniform lane index
-  int ng = 0, k = 0;
-  while (k < K) {
-    const int ks = uni(k);
-    const int a_lvl = bc(t.lvl, ks), a_b = bc(t.b, ks), a_valid = bc(t.valid, ks);
-    const int a_x0 = bc(t.x0, ks), a_x1 = bc(t.x1, ks), a_y0 = bc(t.y0, ks), a_y1 = bc(t.y1, ks);
-    TileGroup g;
-    g.first = k; g.count = 1; g.x0 = a_x0; g.x1 = a_x1; g.y0 = a_y0; g.y1 = a_y1; g.pad = 0;
-    if (!a_valid) g.kind = kGrpAbsent;
-    else if (a_lvl < 0) g.kind = kGrpZero;
-    else {
-      const int ngx0 = (a_x1 >> 2) - (a_x0 >> 2) + 1, th0 = a_y1 - a_y0 + 1, npos0 = th0 * ngx0;
-      if (npos0 > kMaxPos || (4 * npos0 + (npos0 >> 1) + 1) * 16 > win_bytes || bins > NT) {
-        g.kind = kGrpGather;
-      } else {
-        g.kind = kGrpPool;
-        // merge the next RoI of the visiting order while the union window stays a compact patch: at most merge_pct % of the
-        // pixels the members would stage one by one.  (Neighbours of the (level, band, x) order overlap about two-fold, so a
-        // patch of K windows is hardly larger than their sum -- but its rows are K times longer, i.e. whole 128-byte lines.)
-        long long sum_px = (long long)th0 * (a_x1 - a_x0 + 1);
-        while (k + g.count < K && (g.count + 1) * bins <= NT) {
-          const int js = uni(k + g.count);
-          const int n_lvl = bc(t.lvl, js), n_b = bc(t.b, js), n_valid = bc(t.valid, js);
-          if (!n_valid || n_lvl != a_lvl || n_b != a_b) break;
-          const int n_x0 = bc(t.x0, js), n_x1 = bc(t.x1, js), n_y0 = bc(t.y0, js), n_y1 = bc(t.y1, js);
-          const int ux0 = min(g.x0, n_x0), ux1 = max(g.x1, n_x1), uy0 = min(g.y0, n_y0), uy1 = max(g.y1, n_y1);
-          const int ungx = (ux1 >> 2) - (ux0 >> 2) + 1, uth = uy1 - uy0 + 1, unpos = uth * ungx;
-          if (unpos > kMaxPos || (4 * unpos + (unpos >> 1) + 1) * 16 > win_bytes) break;
-          const long long n_px = (long long)(n_y1 - n_y0 + 1) * (n_x1 - n_x0 + 1);
-          const long long u_px = (long long)uth * (ux1 - ux0 + 1);
-          if (u_px * 100 > (sum_px + n_px) * merge_pct) break;
-          g.x0 = ux0; g.x1 = ux1; g.y0 = uy0; g.y1 = uy1; g.count++;
-          sum_px += n_px;
-        }
-      }
-    }
-    emit(ng, g);
-    ng++;
-    k += g.count;
-  }
-  return ng;
-}
-
 // Work item of block b: XCD x (= b % 8) owns a contiguous slice of the (cluster group, channel block) items, as in
 // xcd_work_item, but walks it BACK TO FRONT: the visiting order ends with the coarsest level of an image, whose RoIs have the
 // largest windows and merge least (3-4 clusters per workgroup, 2-2.5 x the average duration).  Started last they were the
@@ -398,7 +326,7 @@ __device__ __forceinline__ int tile_work_item(int b, int n, int reverse) {
   return start + ((reverse & 1) ? qx - 1 - j : j);
 }
 
-template <typename TIn, typename TOut, int NT, bool PREP>
+template <typename TIn, typename TOut, int NT>
 __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct, int reverse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileRoi* troi = reinterpret_cast<TileRoi*>(smem);
@@ -410,26 +338,12 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
   float* win = reinterpret_cast<float*>(smem + kTileHdrBytes + slab_bytes);
   const int win_bytes = lds_bytes - kTileHdrBytes - slab_bytes;
   constexpr int NW = NT / 64;
+  constexpr int kMaxPos = TileShape<NT>::kUnits * NW * 16;                  // 16-byte pieces the register pipeline can carry per quad
   const int tid = threadIdx.x;
   const int nct = ceil_div(p.channels, p.ch_block);
-  int grp, cbi;
-  if (PREP) {
-    // channel-block-MAJOR order inside an XCD's slice of the groups (grid = 8 x ceil(groups / 8) x channel blocks): the ~100
-    // workgroups resident on an XCD pool the same few channels of ~100 neighbouring groups, whose patches (overlapping in x
-    // within a band and in y between bands) then fit that XCD's 4 MB L2 together -- every feature line comes through the
-    // fabric once.  Needs small channel blocks, i.e. the prepared set-up (tile_prep_kernel).
-    const int g8 = (int)(gridDim.x / (kXcds * (unsigned)nct));           // groups per XCD
-    const int x = blockIdx.x % kXcds, j = blockIdx.x / kXcds;
-    cbi = j / g8;
-    const int gl = j - cbi * g8;
-    grp = x * g8 + ((reverse & 1) ? g8 - 1 - gl : gl);
-    if (grp * kgroup >= p.n_rois) return;
-  } else {
-    const int wi = tile_work_item(blockIdx.x, gridDim.x, reverse);
-    grp = wi / nct;
-    cbi = wi - grp * nct;
-  }
-  const int c0 = cbi * p.ch_block;
+  const int wi = tile_work_item(blockIdx.x, gridDim.x, reverse);
+  const int grp = wi / nct;
+  const int c0 = (wi - grp * nct) * p.ch_block;
   const int nc = min(p.ch_block, p.channels - c0);
   const int bins = p.pooled_h * p.pooled_w;
   const int K = kgroup;
@@ -439,17 +353,66 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
   const unsigned long long wall0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  // ---- A + B: windows of the K RoIs and their greedy clustering -- formed here by wavefront 0, or once per launch by
-  // tile_prep_kernel (then this is three loads, whatever the channel block) --------------------------------------------------
-  const TilePrepRoi* prep_rois = reinterpret_cast<const TilePrepRoi*>(p.prep_rois);
-  if (PREP) {
-    const TilePrepGroup* G = reinterpret_cast<const TilePrepGroup*>(p.prep_groups) + grp;
-    if (tid < K) { troi[tid] = prep_rois[(size_t)grp * K + tid].t; tgrp[tid] = G->g[tid]; }
-    if (tid == 0) *ngp = G->ng;
-  } else if (tid < 64) {
+  // ---- A + B (wavefront 0). A: lane k forms the window of RoI k.  B: greedy clustering along the visiting order, by the whole
+  // wave on the register copies (readlane with a uniform index: no LDS round trips, no barrier between A and B) ------------
+  if (tid < 64) {
     TileRoi t;
-    const int ng = tile_windows_and_clusters<NT>(p, grp, K, bins, win_bytes, merge_pct, tid, t, [&](int i, const TileGroup& g) { if (tid == 0) tgrp[i] = g; });
+    t.lvl = -1; t.b = 0; t.x0 = t.x1 = t.y0 = t.y1 = 0; t.r = 0; t.valid = 0; t.sh = t.sw = 0.f; t.bin_h = t.bin_w = 1.f;
+    const int ri = grp * K + tid;
+    if (tid < K && ri < p.n_rois) {
+      const RoiHead hd = load_roi_head(p, ri);
+      t.valid = 1; t.r = hd.r; t.b = hd.b; t.sh = hd.sh; t.sw = hd.sw; t.bin_h = hd.bin_h; t.bin_w = hd.bin_w;
+      if (hd.lvl >= 0 && hd.lvl < p.n_levels) {
+        t.lvl = hd.lvl;
+        const int H = p.lv[hd.lvl].height, W = p.lv[hd.lvl].width;
+        // sample positions are non-decreasing in (bin, sample): first .lo / last .hi bound the window (roi_align_cpu_loop.cpp:38-90)
+        t.y0 = make_axis(hd.sh, hd.bin_h, 0, 0, 2, H).lo;
+        t.y1 = make_axis(hd.sh, hd.bin_h, p.pooled_h - 1, 1, 2, H).hi;
+        t.x0 = make_axis(hd.sw, hd.bin_w, 0, 0, 2, W).lo;
+        t.x1 = make_axis(hd.sw, hd.bin_w, p.pooled_w - 1, 1, 2, W).hi;
+      }
+    }
     if (tid < K) troi[tid] = t;
+    auto bc = [](int v, int k) { return __builtin_amdgcn_readlane(v, k); };     // k: uniform lane index
+    int ng = 0, k = 0;
+    while (k < K) {
+      const int ks = uni(k);
+      const int a_lvl = bc(t.lvl, ks), a_b = bc(t.b, ks), a_valid = bc(t.valid, ks);
+      const int a_x0 = bc(t.x0, ks), a_x1 = bc(t.x1, ks), a_y0 = bc(t.y0, ks), a_y1 = bc(t.y1, ks);
+      TileGroup g;
+      g.first = k; g.count = 1; g.x0 = a_x0; g.x1 = a_x1; g.y0 = a_y0; g.y1 = a_y1; g.pad = 0;
+      if (!a_valid) g.kind = kGrpAbsent;
+      else if (a_lvl < 0) g.kind = kGrpZero;
+      else {
+        const int ngx0 = (a_x1 >> 2) - (a_x0 >> 2) + 1, th0 = a_y1 - a_y0 + 1, npos0 = th0 * ngx0;
+        if (npos0 > kMaxPos || (4 * npos0 + (npos0 >> 1) + 1) * 16 > win_bytes || bins > NT) {
+          g.kind = kGrpGather;
+        } else {
+          g.kind = kGrpPool;
+          // merge the next RoI of the visiting order while the union window stays a compact patch: at most merge_pct % of the
+          // pixels the members would stage one by one.  (Neighbours of the (level, band, x) order overlap about two-fold, so a
+          // patch of K windows is hardly larger than their sum -- but its rows are K times longer, i.e. whole 128-byte lines.)
+          long long sum_px = (long long)th0 * (a_x1 - a_x0 + 1);
+          while (k + g.count < K && (g.count + 1) * bins <= NT) {
+            const int js = uni(k + g.count);
+            const int n_lvl = bc(t.lvl, js), n_b = bc(t.b, js), n_valid = bc(t.valid, js);
+            if (!n_valid || n_lvl != a_lvl || n_b != a_b) break;
+            const int n_x0 = bc(t.x0, js), n_x1 = bc(t.x1, js), n_y0 = bc(t.y0, js), n_y1 = bc(t.y1, js);
+            const int ux0 = min(g.x0, n_x0), ux1 = max(g.x1, n_x1), uy0 = min(g.y0, n_y0), uy1 = max(g.y1, n_y1);
+            const int ungx = (ux1 >> 2) - (ux0 >> 2) + 1, uth = uy1 - uy0 + 1, unpos = uth * ungx;
+            if (unpos > kMaxPos || (4 * unpos + (unpos >> 1) + 1) * 16 > win_bytes) break;
+            const long long n_px = (long long)(n_y1 - n_y0 + 1) * (n_x1 - n_x0 + 1);
+            const long long u_px = (long long)uth * (ux1 - ux0 + 1);
+            if (u_px * 100 > (sum_px + n_px) * merge_pct) break;
+            g.x0 = ux0; g.x1 = ux1; g.y0 = uy0; g.y1 = uy1; g.count++;
+            sum_px += n_px;
+          }
+        }
+      }
+      if (tid == 0) tgrp[ng] = g;
+      ng++;
+      k += g.count;
+    }
     if (tid == 0) *ngp = ng;
   }
   __syncthreads();
@@ -524,15 +487,10 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
     const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
     const TileRoi hd = troi[first + rl];     // sh / sw / bin sizes as phase A formed them
     int ylo[2], yhi[2], xlo[2], xhi[2];      // window-relative: rows premultiplied by the window width
-    AxisEntry pey[2], pex[2];
-    if (PREP) {                              // the prepared axis samples of this lane's (RoI, bin): four 16-byte loads
-      const TilePrepRoi* PR = prep_rois + (size_t)grp * K + first + rl;
-      pey[0] = PR->y[2 * ph]; pey[1] = PR->y[2 * ph + 1]; pex[0] = PR->x[2 * pw]; pex[1] = PR->x[2 * pw + 1];
-    }
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      const AxisEntry ey = PREP ? pey[i] : make_axis(hd.sh, hd.bin_h, ph, i, 2, L.height);
-      const AxisEntry ex = PREP ? pex[i] : make_axis(hd.sw, hd.bin_w, pw, i, 2, L.width);
+      const AxisEntry ey = make_axis(hd.sh, hd.bin_h, ph, i, 2, L.height);
+      const AxisEntry ex = make_axis(hd.sw, hd.bin_w, pw, i, 2, L.width);
       it.yl[i] = ey.l; it.yh[i] = ey.h; it.xl[i] = ex.l; it.xh[i] = ex.h;
       ylo[i] = (ey.lo - gy0) * tw; yhi[i] = (ey.hi - gy0) * tw;
       xlo[i] = ex.lo - g.x0a; xhi[i] = ex.hi - g.x0a;
@@ -555,32 +513,9 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
     for (int i = 0; i < 11; i++) o[i] = tt.acc[i];
     o[11] = wall0; o[12] = __builtin_amdgcn_s_memrealtime();
     o[13] = (unsigned long long)ngroups; o[14] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
-    o[15] = (unsigned long long)(grp * nct + cbi);
+    o[15] = (unsigned long long)wi;
   }
 #endif
-}
-
-// The per-launch preparation pass: one wavefront per group of K RoIs forms what phases A + B and the per-lane item set-up of
-// roi_align_fwd_tile need -- windows, clusters, and the 2 x pooled axis samples of every RoI (pre_calc_for_bilinear_interpolate,
-// roi_align_cpu_loop.cpp:36-95) -- so that the kernel's per-workgroup set-up no longer grows with the number of channel blocks.
-template <int NT>
-__global__ __launch_bounds__(64) void tile_prep_kernel(RoiAlignParams p, int kgroup, int win_bytes, int merge_pct, TilePrepRoi* rois,
-                                                       TilePrepGroup* groups) {
-  const int grp = blockIdx.x, lane = threadIdx.x, K = kgroup;
-  const int bins = p.pooled_h * p.pooled_w;
-  TileRoi t;
-  TilePrepGroup* G = groups + grp;
-  const int ng = tile_windows_and_clusters<NT>(p, grp, K, bins, win_bytes, merge_pct, lane, t, [&](int i, const TileGroup& g) { if (lane == 0) G->g[i] = g; });
-  if (lane == 0) G->ng = ng;
-  if (lane < K) {
-    TilePrepRoi* R = rois + (size_t)grp * K + lane;
-    R->t = t;
-    if (t.valid && t.lvl >= 0) {
-      const int H = p.lv[t.lvl].height, W = p.lv[t.lvl].width;
-      for (int s = 0; s < 2 * p.pooled_h; s++) R->y[s] = make_axis(t.sh, t.bin_h, s >> 1, s & 1, 2, H);
-      for (int s = 0; s < 2 * p.pooled_w; s++) R->x[s] = make_axis(t.sw, t.bin_w, s >> 1, s & 1, 2, W);
-    }
-  }
 }
 
 #ifdef DTC_TILE_TRACE
@@ -615,17 +550,8 @@ static const TileConfig& tile_config() {   // development knobs, resolved ONCE (
   return cfg;
 }
 
-static size_t tile_ws_rois_bytes(int n_rois, int K) {
-  const size_t ngrp = (size_t)ceil_div(n_rois > 0 ? n_rois : 1, K);
-  return (ngrp * K * sizeof(TilePrepRoi) + 255) & ~(size_t)255;
-}
-static size_t tile_ws_bytes(int n_rois, int K) {
-  const size_t ngrp = (size_t)ceil_div(n_rois > 0 ? n_rois : 1, K);
-  return tile_ws_rois_bytes(n_rois, K) + ((ngrp * sizeof(TilePrepGroup) + 255) & ~(size_t)255);
-}
-
 template <typename TIn, typename TOut, int NT>
-static int launch_tile_nt(RoiAlignParams p, hipStream_t stream, void* workspace = nullptr, size_t workspace_bytes = 0) {
+static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   const TileConfig& cfg = tile_config();
   const int bins = p.pooled_h * p.pooled_w;
   int K = cfg.k ? cfg.k : NT / bins;
@@ -636,11 +562,8 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream, void* workspace 
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_tile<TIn, TOut, NT, false>),
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_tile<TIn, TOut, NT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr_rc == hipSuccess)
-      attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_tile<TIn, TOut, NT, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   if (attr_rc != hipSuccess) return DTC_ELAUNCH;
   const int nq_cap = cfg.nq_cap ? cfg.nq_cap : 4;
@@ -651,35 +574,16 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream, void* workspace 
   // 64 -> 0.568, 128 -> 0.545 ms -- the larger block as soon as it still leaves ~8 workgroups per slot
   int cb = cfg.ch_block ? cfg.ch_block : ((long long)ngrp * ceil_div(p.channels, 128) >= 6144 ? 128 : 64);
   while (!cfg.ch_block && cb > 32 && (long long)ngrp * ceil_div(p.channels, cb) < 2048) cb >>= 1;
-  if (workspace) {
-    // prepared launch: the set-up is paid once per launch, so the channel block can be as small as the L2 blocking wants
-    if (workspace_bytes < tile_ws_bytes(p.n_rois, K) || (reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return DTC_EWORKSPACE;
-    if ((p.channels & 3) != 0 || p.pooled_h > kTilePrepAxis / 2 || p.pooled_w > kTilePrepAxis / 2) return DTC_EUNSUPPORTED;
-    TilePrepRoi* prois = reinterpret_cast<TilePrepRoi*>(workspace);
-    TilePrepGroup* pgroups = reinterpret_cast<TilePrepGroup*>(reinterpret_cast<unsigned char*>(workspace) + tile_ws_rois_bytes(p.n_rois, K));
-    const int win_bytes = lds_b - kTileHdrBytes - K * bins * 16 * nq_cap;
-    hipLaunchKernelGGL((tile_prep_kernel<NT>), dim3((unsigned)ngrp), dim3(64), 0, stream, p, K, win_bytes, cfg.merge_pct, prois, pgroups);
-    DTC_CHECK_LAUNCH();
-    p.prep_rois = prois; p.prep_groups = pgroups;
-    cb = cfg.ch_block ? cfg.ch_block : 16;
-    if (cb > p.channels) cb = (p.channels + 3) & ~3;
-    p.ch_block = cb;
-    const int nct = ceil_div(p.channels, p.ch_block);
-    const int g8 = ceil_div(ngrp, kXcds);
-    hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT, true>), dim3((unsigned)(kXcds * g8 * nct)), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, (cfg.reverse ? 1 : 0) | 4);
-    DTC_CHECK_LAUNCH();
-    return DTC_OK;
-  }
   p.ch_block = cb;
   const int nct = ceil_div(p.channels, p.ch_block);
-  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT, false>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, (cfg.reverse ? 1 : 0) | (p.xcd_remap ? 0 : 2));
+  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, (cfg.reverse ? 1 : 0) | (p.xcd_remap ? 0 : 2));
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }
 
 template <typename TIn, typename TOut>
-static int launch_tile_t(const RoiAlignParams& p, hipStream_t stream, void* workspace = nullptr, size_t workspace_bytes = 0) {
-  return launch_tile_nt<TIn, TOut, 256>(p, stream, workspace, workspace_bytes);
+static int launch_tile_t(const RoiAlignParams& p, hipStream_t stream) {
+  return launch_tile_nt<TIn, TOut, 256>(p, stream);
 }
 
 bool roi_align_tile_supported(const RoiAlignParams& p, int in_dtype, int out_dtype) {
@@ -690,32 +594,16 @@ bool roi_align_tile_supported(const RoiAlignParams& p, int in_dtype, int out_dty
          (h && (out_dtype == DTC_F32 || out_dtype == DTC_F16)) || (b && (out_dtype == DTC_F32 || out_dtype == DTC_BF16));
 }
 
-static int launch_tile_typed(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream, void* ws, size_t ws_bytes) {
-  if (p.n_rois == 0) return DTC_OK;
-  if (in_dtype == DTC_F32 && out_dtype == DTC_F32) return launch_tile_t<float, float>(p, stream, ws, ws_bytes);
-  if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return launch_tile_t<__half, float>(p, stream, ws, ws_bytes);
-  if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return launch_tile_t<__half, __half>(p, stream, ws, ws_bytes);
-  if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return launch_tile_t<float, __half>(p, stream, ws, ws_bytes);
-  if (in_dtype == DTC_BF16 && out_dtype == DTC_F32) return launch_tile_t<bf16_t, float>(p, stream, ws, ws_bytes);
-  if (in_dtype == DTC_BF16 && out_dtype == DTC_BF16) return launch_tile_t<bf16_t, bf16_t>(p, stream, ws, ws_bytes);
-  if (in_dtype == DTC_F32 && out_dtype == DTC_BF16) return launch_tile_t<float, bf16_t>(p, stream, ws, ws_bytes);
-  return DTC_EUNSUPPORTED;
-}
-
 int launch_roi_align_tile(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream) {
-  return launch_tile_typed(p, in_dtype, out_dtype, stream, nullptr, 0);
-}
-
-size_t roi_align_tile_workspace_bytes(int n_rois, int pooled_h, int pooled_w) {
-  const int bins = pooled_h * pooled_w;
-  int K = tile_config().k ? tile_config().k : 256 / (bins > 0 ? bins : 1);
-  K = K < 1 ? 1 : (K > kTileMaxK ? kTileMaxK : K);
-  return tile_ws_bytes(n_rois, K);
-}
-
-int launch_roi_align_tile_prepared(const RoiAlignParams& p, int in_dtype, int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  if (!workspace) return DTC_EWORKSPACE;
-  return launch_tile_typed(p, in_dtype, out_dtype, stream, workspace, workspace_bytes);
+  if (p.n_rois == 0) return DTC_OK;
+  if (in_dtype == DTC_F32 && out_dtype == DTC_F32) return launch_tile_t<float, float>(p, stream);
+  if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return launch_tile_t<__half, float>(p, stream);
+  if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return launch_tile_t<__half, __half>(p, stream);
+  if (in_dtype == DTC_F32 && out_dtype == DTC_F16) return launch_tile_t<float, __half>(p, stream);
+  if (in_dtype == DTC_BF16 && out_dtype == DTC_F32) return launch_tile_t<bf16_t, float>(p, stream);
+  if (in_dtype == DTC_BF16 && out_dtype == DTC_BF16) return launch_tile_t<bf16_t, bf16_t>(p, stream);
+  if (in_dtype == DTC_F32 && out_dtype == DTC_BF16) return launch_tile_t<float, bf16_t>(p, stream);
+  return DTC_EUNSUPPORTED;
 }
 
 }  // namespace dtc

@@ -80,10 +80,6 @@ def lib():
     L.dtc_fpn_collect_distribute.argtypes = [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p, i, p]
     L.dtc_roi_align_forward_packed.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, i, i, i, p, i, p]
     L.dtc_roi_align_forward_packed.restype = i
-    L.dtc_roi_align_band_workspace_bytes.argtypes = [i]
-    L.dtc_roi_align_band_workspace_bytes.restype = C.c_size_t
-    L.dtc_roi_align_forward_banded.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, i, i, i, p, i, p, C.c_size_t, p]
-    L.dtc_roi_align_forward_banded.restype = i
     L.dtc_fpn_collect_distribute.restype = i
     L.dtc_postprocess_detections_workspace_bytes.argtypes = [i, i, i]
     L.dtc_postprocess_detections_workspace_bytes.restype = sz
@@ -193,34 +189,6 @@ def roi_align_forward(features, spatial_scales, rois, pooled_h, pooled_w, sampli
             roi_order.to(torch.int32).contiguous().data_ptr() if roi_order is not None else None, R, int(pooled_h),
             int(pooled_w), int(sampling_ratio), out.data_ptr(), _dtype_code(odt), stream_ptr(dev))
     check(rc, "dtc_roi_align_forward")
-    return out
-
-
-def roi_align_forward_banded(features, spatial_scales, roi_desc, pooled_h, pooled_w, sampling_ratio, out_dtype=None,
-                             out=None, workspace_tensor=None):
-    """dtc_roi_align_forward_banded: packed descriptors [R,8] = (batch,x1,y1,x2,y2,level,output row,0) in visiting order.
-
-    Takes the band-sweep kernel where it applies (sampling ratio 2, <= 8x8 bins, fp32 NCHW maps) and the packed entry's
-    kernels otherwise; the output has as many rows as the largest output row + 1 unless `out` is given."""
-    if torch.is_tensor(features):
-        features, spatial_scales = [features], [spatial_scales]
-    dev = _require_cuda(roi_desc, *features)
-    if roi_desc.dtype != torch.float32 or roi_desc.dim() != 2 or roi_desc.shape[1] != 8:
-        raise TypeError("roi_desc must be float32 [R,8]")
-    roi_desc = roi_desc.contiguous()
-    R = roi_desc.shape[0]
-    lv, ch, dt = make_levels(features, spatial_scales)
-    odt = out_dtype or (out.dtype if out is not None else torch.float32)
-    if out is None:
-        rows = int(roi_desc[:, 6].max().item()) + 1 if R else 0
-        out = torch.empty((rows, ch, pooled_h, pooled_w), dtype=odt, device=dev)
-    L = lib()
-    ws = workspace_tensor if workspace_tensor is not None else workspace(L.dtc_roi_align_band_workspace_bytes(R), dev)
-    with torch.cuda.device(dev):
-        rc = L.dtc_roi_align_forward_banded(lv, len(features), ch, _dtype_code(dt), roi_desc.data_ptr(), R, int(pooled_h),
-                                            int(pooled_w), int(sampling_ratio), out.data_ptr(), _dtype_code(odt),
-                                            ws.data_ptr(), ws.numel(), stream_ptr(dev))
-    check(rc, "dtc_roi_align_forward_banded")
     return out
 
 

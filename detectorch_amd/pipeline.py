@@ -63,8 +63,6 @@ class FpnRegionPath:
         self.rois_by_level, self.level_counts, self.idx_restore = e(B, T, 4), e(B, 4, dtype=i32), e(B, T, dtype=i32)
         self.roi_order, self.roi_desc = e(B, T, dtype=i32), e(B, T, 8)
         self.box_feats = e(B * T, self.C, self.box_p, self.box_p, dtype=self.feat_dtype)
-        # per-RoI axis records + band items of the band-sweep RoIAlign kernel (csrc/roi_align_band.hip)
-        self.band_ws = hip.workspace(L.dtc_roi_align_band_workspace_bytes(B * T), dev)
         D = self.max_out
         self.dets, self.det_roi = torch.zeros((B, D, 6), device=dev), torch.zeros((B, D), dtype=i32, device=dev)
         self.det_scaled, self.det_count = torch.zeros((B, D, 4), device=dev), e(B, dtype=i32)
@@ -178,12 +176,9 @@ class FpnRegionPath:
 
     def _roi_align_box(self, st=None):
         st = st or hip.stream_ptr(self.dev)
-        # band-sweep kernel where it applies (fp32 NCHW maps, sampling ratio 2, 7x7 bins); the entry falls through to the
-        # cluster-stationary kernel otherwise.  Bit-identical results either way.
-        hip.check(hip.lib().dtc_roi_align_forward_banded(self.feat_lv, 4, self.C, self.feat_code, self.roi_desc.data_ptr(),
+        hip.check(hip.lib().dtc_roi_align_forward_packed(self.feat_lv, 4, self.C, self.feat_code, self.roi_desc.data_ptr(),
                                                   self.B * self.top_n, self.box_p, self.box_p,
-                                                  self.sr, self.box_feats.data_ptr(), self.out_code, self.band_ws.data_ptr(),
-                                                  self.band_ws.numel() * self.band_ws.element_size(), st), "roi_align(box)")
+                                                  self.sr, self.box_feats.data_ptr(), self.out_code, st), "roi_align(box)")
 
     def _roi_align_mask(self, st=None):
         st = st or hip.stream_ptr(self.dev)

@@ -83,18 +83,6 @@ int dtc_roi_align_forward_packed(const dtc_feat_level* levels, int n_levels, int
                                  const float* roi_desc, int n_rois, int pooled_h, int pooled_w, int sampling_ratio, void* out,
                                  int out_dtype, dtc_stream_t stream);
 
-/* Same contract as dtc_roi_align_forward_packed, with a caller-owned workspace (dtc_roi_align_band_workspace_bytes(n_rois)
- * bytes, 256-byte aligned) that lets the library take the BAND-SWEEP kernel for sampling_ratio 2, <= 8 x 8 bins, float32 NCHW
- * maps (the FPN box head): a workgroup owns 32 feature rows of one level of one image x 8 channels and sweeps them once in x
- * through a sliding LDS window, so a feature row is staged once per band instead of once per cluster of ~5 RoIs.  The
- * descriptors should be in dtc_fpn_collect_distribute's visiting order (level, band of 32 rows, x): any order is correct,
- * that order makes the bands long.  Results are bit-identical to the other entries.  Configurations the sweep does not cover
- * (or workspace == NULL) fall through to dtc_roi_align_forward_packed.  n_rois <= 16384 for the sweep. */
-size_t dtc_roi_align_band_workspace_bytes(int n_rois);
-int dtc_roi_align_forward_banded(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,
-                                 const float* roi_desc, int n_rois, int pooled_h, int pooled_w, int sampling_ratio, void* out,
-                                 int out_dtype, void* workspace, size_t workspace_bytes, dtc_stream_t stream);
-
 /* ---------------------------------------------------------------------------------------------------------------
  * A5  Hard NMS
  * --------------------------------------------------------------------------------------------------------------- */
