@@ -56,7 +56,8 @@ def parse():
     ap.add_argument("--c4-pooled", type=int, default=7, help="cfg2: pooled size (7 as BASELINE names it; 14 = the reference's C4 default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-always", action="store_true", help="run the per-step RCCL all-gather of the detections even at world size 1 (tests: exercises the N > 1 code path on one GPU; needs a launcher environment)")
-    ap.add_argument("--cpu-images", type=int, default=8, help="images of the same workload run on the CPU oracle (timed + compared with the GPU)")
+    ap.add_argument("--cpu-images", type=int, default=8, help="images of the same workload run on the CPU oracle (timed + compared with the GPU); 2 when --gpus > 1")
+    ap.add_argument("--cpu-procs", type=int, default=64, help="worker processes of the image-parallel CPU figure (capped by the host's cores)")
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--sustain-seconds", type=float, default=1.0, help="extra untimed-by-contract run of at least this long, reported under `consistency`")
     ap.add_argument("--inflight", type=int, default=2, help="steps in flight: consecutive steps (independent batches) are issued round-robin on this many HIP streams, so the latency-bound kernels of one step overlap the RoIAlign launches of another")
@@ -77,14 +78,15 @@ def self_launch(a):
 
 
 # ---- CPU baseline (+ the parity check of the benchmarked configuration) -------------------------------------------------
-def _cpu_all_cores(jobs, budget_s=60.0):
-    """All-cores figure: P = min(host cores, 32) worker processes (oracle/cpu_worker.py, one image each, the
-    n distinct images reused round-robin), inputs handed over as memory-mapped .npy files, a file barrier, wall clock from
-    the common start to the last finish.  Returns images/sec over all workers."""
+def _cpu_image_parallel(jobs, budget_s=90.0, max_procs=None):
+    """Image-parallel figure ("one image per process"): P = min(host cores, --cpu-procs) worker processes
+    (oracle/cpu_worker.py, one image each, the n distinct images reused round-robin), inputs handed over as memory-mapped
+    .npy files, a file barrier, wall clock from the common start to the last finish.  Returns images/sec over all workers;
+    `processes` says how many ran (NOT necessarily every core: the field used to be called all_cores)."""
     import shutil
     import tempfile
     n = len(jobs)
-    procs = max(1, min(os.cpu_count() or 1, 32))
+    procs = max(1, min(os.cpu_count() or 1, max_procs or 64))
     need = sum(sum(a.nbytes for a in (j[0] + j[1] + j[2])) + j[3].nbytes + j[4].nbytes + j[5].nbytes for j in jobs) + (1 << 20)
     base = None       # default temp dir unless /dev/shm has room for the inputs (containers often cap it at 64 MB)
     if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2 * need:
@@ -116,7 +118,7 @@ def _cpu_all_cores(jobs, budget_s=60.0):
             time.sleep(0.005)
         spans = [tuple(float(v) for v in open(os.path.join(d, "done%d" % w)).read().split()) for w in range(procs)]
         wall = max(e for _, e in spans) - min(s for s, _ in spans)
-        return {"value": round(procs / wall, 4), "unit": "images/sec", "processes": procs,
+        return {"value": round(procs / wall, 4), "unit": "images/sec", "processes": procs, "host_cpus": os.cpu_count(),
                 "note": "%d worker processes x 1 image each (the %d sample images round-robin), common start, wall clock to the "
                         "last finish; single-threaded oracle port per process" % (procs, n)}
     finally:
@@ -126,7 +128,7 @@ def _cpu_all_cores(jobs, budget_s=60.0):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def cpu_baseline(workload, inputs, path, n_images, c4_pooled):
+def cpu_baseline(workload, inputs, path, n_images, c4_pooled, max_procs=None):
     """Run the CPU checker on the first n_images images of the SAME inputs the timed GPU steps used, (1) time it -- single
     thread: the reference is single-threaded (OpenMP pragma commented out at lib/cppcuda/roi_align_cpu.cpp:136-137; Cython
     loops are serial) -- and (2) compare every intermediate with what the GPU path produced for those images
@@ -193,9 +195,9 @@ def cpu_baseline(workload, inputs, path, n_images, c4_pooled):
                                          "" if workload != "cfg5" else " (fp16 pooled features: rel 1e-3)")}}
     if jobs is not None:
         try:   # informational; the single-core figure above is the contract
-            out["all_cores"] = _cpu_all_cores(jobs)
+            out["image_parallel"] = _cpu_image_parallel(jobs, max_procs=max_procs)
         except Exception as e:
-            out["all_cores"] = {"error": repr(e)}
+            out["image_parallel"] = {"error": repr(e)}
     return out
 
 
@@ -292,13 +294,16 @@ def main():
         gather.finish()
     pipe.count = 0
     dt = timed(a.steps)                      # the contract: exactly K steps, barrier + synchronize on both sides, max over ranks
-    gathered_ok = None
+    gathered_ok, gathered_copy = None, None
+    s_last = (a.steps - 1) % NSETS
     if gather is not None:                   # what every rank received for THIS rank's last step == what the path holds
         gd, gc = gather.finish()
-        pl = paths[(a.steps - 1) % NSETS]
+        pl = paths[s_last]
         gathered_ok = bool(torch.equal(gd[rank], pl.dets) and torch.equal(gc[rank], pl.det_count))
         if not gathered_ok:
             raise SystemExit("all-gathered detections differ from the local result")
+        if rank == 0:                        # kept for the cross-rank check below (the staging buffers are reused by later steps)
+            gathered_copy = (gd.clone(), gc.clone())
     # a longer run of the same loop (>= --sustain-seconds): the contract region is only K steps long
     n_sus = int(max(a.steps, np.ceil(a.sustain_seconds / max(dt / a.steps, 1e-6)))) if a.sustain_seconds > 0 else 0
     if dist is not None and n_sus:
@@ -324,12 +329,44 @@ def main():
     alg_bytes = paths[0].box_roialign_bytes()
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
+    # ---- N > 1: the rows rank 0 RECEIVED from every other rank == what those ranks' inputs give when recomputed here ---------
+    # ("verify gathered detections are bit-identical to the W=1 run".  Rank r's input set s is the deterministic
+    # synthetic batch of seed base + 500 s + r, so rank 0 regenerates it, runs the path eagerly on its own GPU and compares
+    # with the gathered rows of rank r's last timed step.  No collective is involved; the other ranks wait at the barrier.)
+    recomputed_ok = None
+    if gathered_copy is not None and world > 1:
+        gd0, gc0 = gathered_copy
+        base = {"cfg3": 3000, "cfg5": 5000, "cfg2": 2000}[wl]
+        pv = paths[s_last]
+        recomputed_ok = True
+        for r in range(1, world):
+            seed_r = base + 500 * s_last + r
+            inp_r = (synthetic_c4_batch(a.batch, dev, seed=seed_r, feat_dtype=fdt) if wl == "cfg2" else
+                     synthetic_batch(a.batch, dev, seed=seed_r, top_n=top_n, feat_dtype=fdt, channels_last=a.channels_last))
+            pv.bind(*inp_r)
+            pv.step(use_graph=False)         # eager: the captured graph holds the pointers of the original input set
+            torch.cuda.synchronize(dev)
+            ok_r = bool(torch.equal(gd0[r], pv.dets) and torch.equal(gc0[r], pv.det_count))
+            recomputed_ok = recomputed_ok and ok_r
+            del inp_r
+        pv.bind(*inputs[s_last])             # restore (the roofline launches and the CPU check below use the original inputs)
+        pv.step(use_graph=False)
+        torch.cuda.synchronize(dev)
+        if not recomputed_ok:
+            raise SystemExit("detections gathered from another rank differ from their recomputation on rank 0")
+
     traffic, traffic_src = None, None
     try:   # HBM-side bytes per launch of the same kernel/config: rocprofv3 --pmc passes, committed (profiles/README.md)
         tj = json.load(open(os.path.join(ROOT, "profiles", "roialign_traffic.json")))
         key = "%s_b%d_%s_%s" % (wl, a.batch, "nhwc" if a.channels_last else "nchw", "f16" if fp16 else "f32")
         if key in tj:
-            traffic, traffic_src = tj[key], "profiles/roialign_traffic.json[%s] (rocprofv3 --pmc TCC_EA0_* passes, tools/collect_profiles.sh; not measured in this run)" % key
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from kernel_hash import kernel_sha16
+            stamped = tj.get(key + "_detail", {}).get("kernel_sha16")
+            if stamped == kernel_sha16(wl):      # the counters were collected on THIS kernel source
+                traffic, traffic_src = tj[key], "profiles/roialign_traffic.json[%s] (rocprofv3 --pmc TCC_EA0_* passes, tools/collect_profiles.sh; not measured in this run; kernel source hash %s matches)" % (key, stamped)
+            else:
+                traffic_src = "profiles/roialign_traffic.json[%s] is stale: collected on kernel source %s, running %s" % (key, stamped, kernel_sha16(wl))
     except Exception:
         pass
 
@@ -371,14 +408,17 @@ def main():
                                   "formed with the reference's unfused multiply-adds -- i.e. VALU issue, not HBM (DESIGN 3.6)") if wl == "cfg2" else
                                  "TCP line-fill rate / EA bandwidth of the re-fetched window rows (DESIGN 3.1)"},
             "consistency": {"timed_region_s": round(dt, 4), "gathered_equals_local": gathered_ok,
+                            "gathered_equals_recomputed": recomputed_ok,
                             "sustained": None if dt_sus is None else {"steps": n_sus, "seconds": round(dt_sus, 3),
                                                                       "ms_per_step": round(dt_sus / n_sus * 1e3, 4),
                                                                       "images_per_sec": round(a.batch * n_sus * world / dt_sus, 2)}},
         }
-        if not a.no_cpu_baseline and world == 1 and not isinstance(p0, OverlappedRegionPath):
+        if not a.no_cpu_baseline and not isinstance(p0, OverlappedRegionPath):
             p0.step(use_graph=not a.eager)          # the configuration that was timed, on input set 0
             torch.cuda.synchronize(dev)
-            out["cpu_baseline"] = cpu_baseline(wl, inputs[0], p0, a.cpu_images, a.c4_pooled)
+            # rank 0 only; at N > 1 a shorter sample (the other ranks wait at the final barrier meanwhile)
+            out["cpu_baseline"] = cpu_baseline(wl, inputs[0], p0, a.cpu_images if world == 1 else min(a.cpu_images, 2), a.c4_pooled,
+                                               max_procs=a.cpu_procs)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

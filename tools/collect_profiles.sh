@@ -37,6 +37,20 @@ for g, cs in raw.items():
     wr = 64 * w64 + 32 * (a.get("TCC_EA0_WRREQ_sum", 0) - w64)
     res[str(g)] = {"read_bytes": rd, "write_bytes": wr, "counters": a}
 json.dump(res, open(out + "/traffic.json", "w"), indent=1)
+# the entry for profiles/roialign_traffic.json, stamped with the hash of the kernel source the counters were collected on
+import os, sys
+sys.path.insert(0, "tools")
+from kernel_hash import kernel_sha16
+wl = "cfg3"
+for tok in os.environ.get("BENCH_ARGS", "").split():
+    if tok in ("cfg2", "cfg3", "cfg5"): wl = tok
+if res:
+    g = max(res, key=lambda k: int(k))
+    key = "%s_b8_nchw_%s" % (wl, "f16" if wl == "cfg5" else "f32")
+    entry = {key: int(res[g]["read_bytes"] + res[g]["write_bytes"]),
+             key + "_detail": {"grid": int(g), "read_bytes": int(res[g]["read_bytes"]), "write_bytes": int(res[g]["write_bytes"]),
+                               "kernel_sha16": kernel_sha16(wl), "source": "profiles/<round>_roialign_%s_pmc_raw.json" % wl}}
+    json.dump(entry, open(out + "/traffic_entry.json", "w"), indent=1)
 # the box-head launch is the one with the largest grid; bench.py reports its read + write bytes as roofline.traffic
 if res:
     g = max(res, key=lambda k: int(k))
