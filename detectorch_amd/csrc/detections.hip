@@ -23,6 +23,7 @@ struct DetParams {
   const float* cls_score;    // [B, R, n_cls]  probabilities, or LOGITS when sm_stats != NULL
   const double* sm_stats;    // [B, R, 2] = (row max, sum_j exp(l_j - max)) of the class logits, or NULL
   const float* bbox_pred;    // [B, R, 4*n_cls]
+  const float* decoded;      // [B, R, 4*n_cls] already decoded + clipped boxes (box_results_with_nms_and_limit's input), or NULL
   const float* scale;        // [B] scaling factor per image
   const float* im_size;      // [B, 2] original (h, w)
   int R, n_cls;
@@ -129,10 +130,16 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
   block_bitonic_sort<kDetThreads>(keys, np2);
   DTC_PT(0, ptb, 2);
   // decode candidate q (once), then emit both the candidate-order and the score-order copies
-  const float sf = p.scale[b];
-  const float im_h = p.im_size[b * 2 + 0], im_w = p.im_size[b * 2 + 1];
   float4* qb = reinterpret_cast<float4*>(p.q_boxes) + (size_t)seg * p.R;
-  for (int q = tid; q < n; q += kDetThreads) {
+  if (p.decoded) {          // lib/utils/result_utils.py:128: boxes[inds, j * 4:(j + 1) * 4] taken as they are
+    for (int q = tid; q < n; q += kDetThreads) {
+      const float* d = p.decoded + ((size_t)b * p.R + qroi[q]) * 4 * p.n_cls + 4 * j;
+      qb[q] = make_float4(d[0], d[1], d[2], d[3]);
+    }
+  }
+  const float sf = p.decoded ? 1.f : p.scale[b];
+  const float im_h = p.decoded ? 0.f : p.im_size[b * 2 + 0], im_w = p.decoded ? 0.f : p.im_size[b * 2 + 1];
+  for (int q = tid; q < n && !p.decoded; q += kDetThreads) {
     const int r = qroi[q];
     const float* roi = p.rois5 + ((size_t)b * p.R + r) * 5 + 1;
     const float* d = p.bbox_pred + ((size_t)b * p.R + r) * 4 * p.n_cls + 4 * j;
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
   __syncthreads();
   DTC_PT(1, b, 4);
   // ---- pass B: class-major, candidate(roi)-ascending output (:143 dets_j[keep], :165 vstack) ----
-  const float sf = p.scale[b];
+  const float sf = p.scale ? p.scale[b] : 1.f;
   for (int c = wv; c < nseg; c += kFinThreads / 64) {
     const int seg = seg0 + c, nk = koff[c + 1] - koff[c];
     if (ccnt[c] == 0) continue;
@@ -360,7 +367,7 @@ DTC_API size_t dtc_postprocess_detections_workspace_bytes(int batch, int max_roi
 }
 
 static int postprocess_detections_impl(const float* rois5, const int32_t* n_rois, const float* cls_score, int scores_are_logits,
-                                       const float* bbox_pred, const float* scaling_factor, const float* im_size,
+                                       const float* bbox_pred, const float* decoded_boxes, const float* scaling_factor, const float* im_size,
                                        int batch, int max_rois, int n_cls, float wx, float wy, float ww, float wh,
                                        float score_thresh, float nms_thresh, int max_det, void* workspace,
                                        size_t workspace_bytes, float* dets, int32_t* det_roi, float* det_rois_scaled,
@@ -368,8 +375,9 @@ static int postprocess_detections_impl(const float* rois5, const int32_t* n_rois
   if (batch < 0 || max_rois < 1 || n_cls < 2 || n_cls - 1 > dtc::kFinMaxCls || max_out < 1) return DTC_EINVAL;
   if (batch == 0) return DTC_OK;
   if (max_rois > 4096) return DTC_EUNSUPPORTED;
-  if (!rois5 || !cls_score || !bbox_pred || !scaling_factor || !im_size || !workspace || !dets || !det_roi || !det_count)
-    return DTC_EINVAL;
+  if (!cls_score || !workspace || !dets || !det_roi || !det_count) return DTC_EINVAL;
+  if (!decoded_boxes && (!rois5 || !bbox_pred || !scaling_factor || !im_size)) return DTC_EINVAL;
+  if (decoded_boxes && det_rois_scaled) return DTC_EINVAL;
   const dtc::DetPlan pl = dtc::det_plan(batch, max_rois, n_cls);
   if (workspace_bytes < pl.total) return DTC_EWORKSPACE;
   unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
@@ -377,6 +385,7 @@ static int postprocess_detections_impl(const float* rois5, const int32_t* n_rois
   const int S = batch * (n_cls - 1);
   dtc::DetParams p;
   p.rois5 = rois5; p.n_rois = n_rois; p.cls_score = cls_score; p.bbox_pred = bbox_pred; p.scale = scaling_factor;
+  p.decoded = decoded_boxes;
   p.sm_stats = nullptr;
   if (scores_are_logits) {
     double* st = reinterpret_cast<double*>(w + pl.sm_stats);
@@ -414,7 +423,7 @@ DTC_API int dtc_postprocess_detections(const float* rois5, const int32_t* n_rois
                                        float score_thresh, float nms_thresh, int max_det, void* workspace,
                                        size_t workspace_bytes, float* dets, int32_t* det_roi, float* det_rois_scaled,
                                        int32_t* det_count, int max_out, dtc_stream_t stream) {
-  return postprocess_detections_impl(rois5, n_rois, cls_score, 0, bbox_pred, scaling_factor, im_size, batch, max_rois, n_cls, wx,
+  return postprocess_detections_impl(rois5, n_rois, cls_score, 0, bbox_pred, nullptr, scaling_factor, im_size, batch, max_rois, n_cls, wx,
                                      wy, ww, wh, score_thresh, nms_thresh, max_det, workspace, workspace_bytes, dets, det_roi,
                                      det_rois_scaled, det_count, max_out, stream);
 }
@@ -425,7 +434,17 @@ DTC_API int dtc_postprocess_detections_logits(const float* rois5, const int32_t*
                                               float score_thresh, float nms_thresh, int max_det, void* workspace,
                                               size_t workspace_bytes, float* dets, int32_t* det_roi, float* det_rois_scaled,
                                               int32_t* det_count, int max_out, dtc_stream_t stream) {
-  return postprocess_detections_impl(rois5, n_rois, cls_logits, 1, bbox_pred, scaling_factor, im_size, batch, max_rois, n_cls, wx,
+  return postprocess_detections_impl(rois5, n_rois, cls_logits, 1, bbox_pred, nullptr, scaling_factor, im_size, batch, max_rois, n_cls, wx,
                                      wy, ww, wh, score_thresh, nms_thresh, max_det, workspace, workspace_bytes, dets, det_roi,
                                      det_rois_scaled, det_count, max_out, stream);
+}
+
+DTC_API int dtc_box_results_nms_limit(const float* scores, const float* boxes, const int32_t* n_rois, int batch, int max_rois,
+                                      int n_cls, float score_thresh, float nms_thresh, int max_det, void* workspace,
+                                      size_t workspace_bytes, float* dets, int32_t* det_roi, int32_t* det_count, int max_out,
+                                      dtc_stream_t stream) {
+  if (!boxes) return DTC_EINVAL;
+  return postprocess_detections_impl(nullptr, n_rois, scores, 0, nullptr, boxes, nullptr, nullptr, batch, max_rois, n_cls, 1.f, 1.f,
+                                     1.f, 1.f, score_thresh, nms_thresh, max_det, workspace, workspace_bytes, dets, det_roi,
+                                     nullptr, det_count, max_out, stream);
 }

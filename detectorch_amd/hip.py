@@ -87,6 +87,8 @@ def lib():
     L.dtc_postprocess_detections.restype = i
     L.dtc_postprocess_detections_logits.argtypes = L.dtc_postprocess_detections.argtypes
     L.dtc_postprocess_detections_logits.restype = i
+    L.dtc_box_results_nms_limit.argtypes = [p, p, p, i, i, i, f, f, i, p, sz, p, p, p, i, p]
+    L.dtc_box_results_nms_limit.restype = i
     L.dtc_mask_paste.argtypes = [p, p, i, i, p, p, p, i, i, f, i, p, ll, p, p, p, p, p]
     L.dtc_mask_paste.restype = i
     L.dtc_mask_rle.argtypes = [p, ll, p, p, p, p, i, i, p, i, p, p, i, p, p]
@@ -370,6 +372,28 @@ def postprocess_detections(rois5, n_rois, cls_score, bbox_pred, scaling_factor, 
                                            det_scaled.data_ptr(), det_count.data_ptr(), int(max_out), stream_ptr(dev))
     check(rc, "dtc_postprocess_detections")
     return dets, det_roi, det_scaled, det_count
+
+
+def box_results_nms_limit(scores, boxes, n_rois=None, score_thresh=0.05, nms_thresh=0.5, max_det=100, max_out=None, ws=None):
+    """dtc_box_results_nms_limit: scores [B,R,C], decoded boxes [B,R,4C] -> (dets [B,max_out,6], det_roi [B,max_out], det_count [B])"""
+    dev = _require_cuda(scores, boxes, n_rois)
+    B, R, ncls = scores.shape
+    if max_out is None:
+        max_out = 128 if max_det > 0 else R * (ncls - 1)
+    L_ = lib()
+    need = L_.dtc_postprocess_detections_workspace_bytes(B, R, ncls)
+    if ws is None or ws.numel() < need:
+        ws = workspace(need, dev)
+    dets = torch.zeros((B, max_out, 6), dtype=torch.float32, device=dev)
+    det_roi = torch.zeros((B, max_out), dtype=torch.int32, device=dev)
+    det_count = torch.empty((B,), dtype=torch.int32, device=dev)
+    scores, boxes = scores.contiguous(), boxes.contiguous()
+    with torch.cuda.device(dev):
+        rc = L_.dtc_box_results_nms_limit(scores.data_ptr(), boxes.data_ptr(), _ptr(n_rois), B, R, ncls, float(score_thresh),
+                                          float(nms_thresh), int(max_det), ws.data_ptr(), ws.numel(), dets.data_ptr(),
+                                          det_roi.data_ptr(), det_count.data_ptr(), int(max_out), stream_ptr(dev))
+    check(rc, "dtc_box_results_nms_limit")
+    return dets, det_roi, det_count
 
 
 def mask_paste(masks, dets, det_count, im_size, M, per_image_capacity, mask_index=None, thresh=0.5, cls_specific=True):

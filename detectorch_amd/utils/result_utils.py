@@ -87,9 +87,23 @@ def postprocess_output(rois, scaling_factor, im_size, class_scores, bbox_deltas,
 def box_results_with_nms_and_limit(scores, boxes, num_classes=81, score_thresh=0.05, overlap_thresh=0.5,
                                    do_soft_nms=False, soft_nms_sigma=0.5, soft_nms_method='linear', do_bbox_vote=False,
                                    bbox_vote_thresh=0.8, bbox_vote_method='ID', max_detections_per_img=100):
-    """result_utils.py:96-168 on already decoded+clipped boxes [R,4*num_classes] (numpy in / numpy out)."""
+    """result_utils.py:96-168 on already decoded+clipped boxes [R,4*num_classes] (numpy in / numpy out).
+    The default branch (hard NMS, no bbox vote) is ONE pass on the device -- threshold, 80-class segmented NMS, the top-100
+    limit, one copy back (dtc_box_results_nms_limit); the reference runs 80 Python iterations, each a host NMS call.
+    Soft-NMS and bbox voting keep the reference's per-class structure on their own kernels."""
     scores = np.ascontiguousarray(scores, np.float32)
     boxes = np.ascontiguousarray(boxes, np.float32)
+    if not do_soft_nms and not do_bbox_vote and scores.shape[0] <= 4096 and scores.shape[0] > 0 and num_classes > 1:
+        dev = _dev()
+        R = scores.shape[0]
+        sc = torch.from_numpy(scores[:, :num_classes]).to(dev).reshape(1, R, num_classes)
+        bx = torch.from_numpy(boxes[:, :4 * num_classes]).to(dev).reshape(1, R, 4 * num_classes)
+        max_out = 256 if max_detections_per_img > 0 else R * (num_classes - 1)
+        dets, _, cnt = hip.box_results_nms_limit(sc, bx, None, score_thresh, overlap_thresh, max_detections_per_img, max_out)
+        n = int(cnt[0].item())
+        if n > dets.shape[1]:            # more than max_out rows tie at the limit score (:161 keeps them all)
+            dets, _, cnt = hip.box_results_nms_limit(sc, bx, None, score_thresh, overlap_thresh, max_detections_per_img, n)
+        return _split_by_class(dets[0].cpu().numpy(), n, num_classes)
     cls_boxes = [[] for _ in range(num_classes)]
     for j in range(1, num_classes):
         inds = np.where(scores[:, j] > score_thresh)[0]

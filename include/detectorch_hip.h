@@ -209,6 +209,17 @@ int dtc_postprocess_detections_logits(const float* rois5, const int32_t* n_rois,
                                       int32_t* det_roi, float* det_rois_scaled, int32_t* det_count, int max_out,
                                       dtc_stream_t stream);
 
+/* box_results_with_nms_and_limit (hard NMS) of lib/utils/result_utils.py:96-168 on ALREADY decoded + clipped boxes, for a
+ * batch, in one pass on the device (the reference: 80 Python iterations, each a host NMS call):
+ *   scores [B,R,n_cls], boxes [B,R,4*n_cls] (class j in columns 4j..4j+3), n_rois int32 [B] (NULL: R).
+ * Per class j >= 1: score > score_thresh (:127), NMS at nms_thresh (:142); if more than max_det survive in total, those
+ * with score >= the max_det-th largest (:159-163; max_det 0: unlimited).  Outputs as dtc_postprocess_detections (dets
+ * [B,max_out,6] ordered by class then by row, det_roi = source row, det_count = true number).  Same workspace size. */
+int dtc_box_results_nms_limit(const float* scores, const float* boxes, const int32_t* n_rois, int batch, int max_rois,
+                              int n_cls, float score_thresh, float nms_thresh, int max_det, void* workspace,
+                              size_t workspace_bytes, float* dets, int32_t* det_roi, int32_t* det_count, int max_out,
+                              dtc_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * A9  Mask resize + binarise (+ paste geometry)
  * --------------------------------------------------------------------------------------------------------------- */

@@ -142,6 +142,37 @@ def test_box_results_with_nms_and_limit_golden(hip):
         assert np.array_equal(sc, ref_s) and np.array_equal(bx, ref_b)
 
 
+@pytest.mark.parametrize("R,max_det", [(1000, 100), (700, 0)])
+def test_box_results_nms_limit_batched_device_entry(hip, oracle, R, max_det):
+    """dtc_box_results_nms_limit (result_utils.py:96-168 on ALREADY decoded boxes, one pass on the device, batched) against the
+    oracle: the boxes are decoded + clipped on the host exactly as postprocess_output does (:76-84: rois / scale, bbox_transform
+    with (10,10,5,5), clip_tiled_boxes), then threshold / per-class NMS / limit must give what the oracle's whole chain gives."""
+    B = 2
+    rs = synth.rng(6, R + max_det)
+    n_rois = np.array([R, R - 41], np.int32)
+    sf = np.array([1.6, 1.25], np.float32)
+    im = np.array([[500, 833], [640, 960]], np.float32)
+    cls = np.zeros((B, R, 81), np.float32)
+    dec = np.zeros((B, R, 324), np.float32)
+    refs = []
+    for b in range(B):
+        rois = synth.make_rois(rs, R)
+        cls[b], dl = synth.make_head_outputs(rs, R)
+        boxes = (rois / sf[b]).astype(np.float32)
+        dec[b] = oracle.clip_tiled_boxes(oracle.bbox_transform(boxes, dl, (10.0, 10.0, 5.0, 5.0)), im[b, 0], im[b, 1])
+        n = n_rois[b]
+        refs.append(oracle.postprocess_detections(rois[:n], sf[b], im[b], cls[b, :n], dl[:n], max_det=max_det))
+    cap = 4096
+    dets, roi, cnt = hip.box_results_nms_limit(cu(cls), cu(dec), cu(n_rois), max_det=max_det, max_out=cap)
+    for b in range(B):
+        rd, rr = refs[b]
+        c = int(cnt[b])
+        assert c == rd.shape[0]
+        c = min(c, cap)
+        assert np.array_equal(dets[b, :c].cpu().numpy(), rd[:c])
+        assert np.array_equal(roi[b, :c].cpu().numpy(), rr[:c])
+
+
 @pytest.mark.parametrize("R,max_det", [(1000, 100), (1000, 0), (300, 100), (2000, 100)])
 def test_postprocess_batched_vs_oracle(hip, oracle, R, max_det):
     B = 2
