@@ -99,7 +99,8 @@ __device__ __forceinline__ void block_bitonic_sort(uint64_t* keys, int n_pow2) {
   else if (per == 2) block_bitonic_sort_regs<THREADS, 2>(keys, n_pow2);
   else if (per == 4) block_bitonic_sort_regs<THREADS, 4>(keys, n_pow2);
   else if (per == 8) block_bitonic_sort_regs<THREADS, 8>(keys, n_pow2);
-  else block_bitonic_sort_regs<THREADS, 16>(keys, n_pow2);
+  else if (per == 16) block_bitonic_sort_regs<THREADS, 16>(keys, n_pow2);
+  else __builtin_trap();        // more than 16 keys per thread: no instantiation sorts that (callers bound n_pow2 on the host)
 }
 
 __host__ __device__ __forceinline__ int next_pow2(int n) {

@@ -16,6 +16,9 @@ __device__ __forceinline__ void select_digit(const uint32_t* __restrict__ h, int
   __shared__ uint32_t sd_wtot[4];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int per = nbins >> 8;
+  // contract: every thread of the workgroup calls this, blockDim.x >= 256, nbins a multiple of 256 and <= 4096,
+  // a 16-byte aligned histogram when nbins is a multiple of 1024
+  if (blockDim.x < 256 || (nbins & 255) != 0 || per > 16 || ((per & 3) == 0 && (reinterpret_cast<uintptr_t>(h) & 15) != 0)) __builtin_trap();
   uint32_t loc[16];
   uint32_t part = 0, suf = 0;
   if (t < 256) {

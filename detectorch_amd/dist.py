@@ -91,6 +91,7 @@ class ResultGatherer:
 
     def __init__(self, imgs_per_rank, max_out, device, world, str_stride=512, group=None):
         self.per, self.D, self.world, self.group, self.stride = imgs_per_rank, max_out, world, group, int(str_stride)
+        assert (max_out * self.stride) % 4 == 0, "max_out * str_stride must be a multiple of 4 (the record is viewed as int32 / float32)"
         self.o_cnt = max_out * 24
         self.o_sz = self.o_cnt + 4
         self.o_len = self.o_sz + 8

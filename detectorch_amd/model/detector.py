@@ -220,7 +220,8 @@ class detector(nn.Module):
         self.fuse_rpn_sigmoid = bool(fuse_rpn_sigmoid)   # extension: RPN sigmoid folded into the top-k kernel (same outputs)
         self.head_dtype = head_dtype    # extension: torch.bfloat16 / float16 -> pooled features + fc6/fc7 in that dtype (MFMA GEMMs)
         self.N_classes = N_classes
-        self._paths = {}
+        self._paths = {}               # (B, padded h, padded w, device) -> FpnRegionPath, least recently used first
+        self.max_cached_paths = 4
         if train:
             raise NotImplementedError("detectorch_amd.detector is inference-only")
         self.roi_height, self.roi_width = int(roi_height), int(roi_width)
@@ -341,7 +342,14 @@ class detector(nn.Module):
     def _region_path(self, B, h, w, dev):
         from ..pipeline import FpnRegionPath
         key = (B, h, w, str(dev))
-        if key not in self._paths:
+        if key in self._paths:
+            self._paths[key] = self._paths.pop(key)          # most recently used last
+        else:
+            # a path owns ~100 MB of workspaces per image of batch: keep the few most recently used padded sizes only (a COCO
+            # evaluation sees dozens).  NOTE the returned path is the cached object: its result tensors are overwritten by the
+            # next forward_batched call with the same (B, h, w) -- copy what has to outlive that call.
+            while len(self._paths) >= self.max_cached_paths:
+                self._paths.pop(next(iter(self._paths)))
             self._paths[key] = FpnRegionPath(B, dev, channels=256, n_cls=self.N_classes, pad_h=h, pad_w=w, cls_logits=True,
                                              with_rle=self.use_mask_head, box_pooled=self.roi_height, mask_pooled=14,
                                              sampling_ratio=self.roi_sampling_ratio,

@@ -417,8 +417,10 @@ class StepPipeline:
         if st is None:
             p.step(use_graph=use_graph)
         else:
-            if i < len(self.paths):
-                st.wait_stream(torch.cuda.current_stream(self.dev))   # inputs bound on the caller's stream
+            # whatever the caller enqueued on ITS stream before this call (binding inputs at first, refilling the bound input
+            # tensors between steps later) is ordered before the step; the converse -- do not overwrite the inputs of a step
+            # that is still running -- is the caller's: enqueue the refill on the returned stream, or synchronize() first
+            st.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(st):
                 p.step(use_graph=use_graph)
         return p, st
