@@ -745,7 +745,7 @@ static int launch_typed(int kind, const RoiAlignParams& p, int in_dtype, int out
 static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype, const float* rois,
                              int roi_cols, const int32_t* roi_levels, const int32_t* roi_order, const float* roi_desc,
                              int n_rois, int pooled_h, int pooled_w, int sampling_ratio, void* out, int out_dtype,
-                             dtc_stream_t stream) {
+                             dtc_stream_t stream, void* workspace = nullptr, size_t workspace_bytes = 0) {
   if (!levels || n_levels < 1 || n_levels > DTC_MAX_LEVELS || channels < 1 || n_rois < 0 || pooled_h < 1 ||
       pooled_w < 1 || (roi_cols != 4 && roi_cols != 5) || (n_rois > 0 && ((!rois && !roi_desc) || !out)))
     return DTC_EINVAL;
@@ -780,7 +780,7 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   if (lds_ok && all_nhwc && few_taps && cfg.nhwc_direct) return dtc::launch_typed(dtc::kKernNhwc, p, in_dtype, out_dtype, s);
   // one level whose whole map fits LDS (the C4 heads), adaptive sampling: the map-stationary kernel (roi_align_map.hip)
   if (cfg.map && !cfg.general && sampling_ratio != 2 && dtc::roi_align_map_supported(p, in_dtype, out_dtype))
-    return dtc::launch_roi_align_map(p, in_dtype, out_dtype, s);
+    return dtc::launch_roi_align_map_ws(p, in_dtype, out_dtype, workspace, workspace_bytes, s);
   // NCHW (the reference's layout), sampling_ratio 2: the cluster-stationary kernel (roi_align_tile.hip)
   if (cfg.tile && !all_nhwc && !cfg.general && dtc::roi_align_tile_supported(p, in_dtype, out_dtype))
     return dtc::launch_roi_align_tile(p, in_dtype, out_dtype, s);
@@ -800,6 +800,15 @@ DTC_API int dtc_roi_align_forward_packed(const dtc_feat_level* levels, int n_lev
                                             int sampling_ratio, void* out, int out_dtype, dtc_stream_t stream) {
   return roi_align_dispatch(levels, n_levels, channels, in_dtype, nullptr, 5, nullptr, nullptr, roi_desc, n_rois, pooled_h,
                             pooled_w, sampling_ratio, out, out_dtype, stream);
+}
+
+DTC_API size_t dtc_roi_align_workspace_bytes(int n_rois) { return dtc::roi_align_map_workspace_bytes(n_rois); }
+
+DTC_API int dtc_roi_align_forward_packed_ws(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,
+                                            const float* roi_desc, int n_rois, int pooled_h, int pooled_w, int sampling_ratio,
+                                            void* out, int out_dtype, void* workspace, size_t workspace_bytes, dtc_stream_t stream) {
+  return roi_align_dispatch(levels, n_levels, channels, in_dtype, nullptr, 5, nullptr, nullptr, roi_desc, n_rois, pooled_h,
+                            pooled_w, sampling_ratio, out, out_dtype, stream, workspace, workspace_bytes);
 }
 
 DTC_API int dtc_roi_align_forward(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,

@@ -18,6 +18,9 @@ struct RoiAlignParams {
   int ch_block;   // channels per workgroup of the LDS kernel (multiple of 64): setup (tables, window) is paid once per block
   int cts64;      // 1: allow 64-channel sub-tiles (one bin per ds_read_b128 lane group: conflict-free taps)
   int xcd_remap;  // 1: workgroup -> work-item mapping keeps each XCD on a contiguous range of the visiting order
+  // map-stationary kernel only: per-RoI records formed once per launch by map_prep_kernel (geometry, axis samples), so that the
+  // 128 channel-group workgroups that pool a RoI do not each re-derive them (nullptr: derived in the kernel)
+  const void* prep = nullptr;
 };
 
 // XCD-aware work assignment.  The dispatcher deals workgroups round-robin over the 8 XCDs (workgroup b runs on XCD b % 8)
@@ -116,5 +119,7 @@ int launch_roi_align_tile(const RoiAlignParams& p, int in_dtype, int out_dtype, 
 // launchers of the map-stationary kernel (roi_align_map.hip): single-level inputs whose whole map fits LDS
 bool roi_align_map_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
 int launch_roi_align_map(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream);
+size_t roi_align_map_workspace_bytes(int n_rois);      // per-launch preparation records (optional: workspace == nullptr -> none)
+int launch_roi_align_map_ws(const RoiAlignParams& p, int in_dtype, int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace dtc

@@ -20,6 +20,8 @@
 //     and leave as 16-byte stores.
 // RoIs must arrive image-major (the packed descriptors of dtc_fpn_collect_distribute are); any order is CORRECT, but every
 // change of image re-stages the map.
+#include <stdlib.h>
+
 #include <mutex>
 
 #include "roi_align_common.h"
@@ -79,7 +81,58 @@ __device__ __forceinline__ void map_sample(const char* map, int plane_bytes, int
 
 __device__ __forceinline__ int map_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <typename TIn, typename TOut, int NQ>
+// Per-RoI record of the per-launch preparation pass (map_prep_kernel): everything about a RoI that does not depend on the
+// channels -- which each of the C / 8 channel-group workgroups used to re-derive (two IEEE divisions for the bin sizes, two
+// more for the adaptive grid, one make_axis per lane and axis: ~170 of the ~350 instructions a wavefront spent per RoI
+// outside the sample loops).  hdr[]: word k is fetched by lane k and read with readlane.
+enum { kMhR = 0, kMhB, kMhFlags, kMhGh, kMhGw, kMhInv, kMhCount, kMhRcpLo, kMhRcpHi, kMhSh, kMhSw, kMhBinH, kMhBinW, kMhWords = 64 };
+enum { kMfPad = 1, kMfYtab = 2, kMfXtab = 4 };
+struct MapAxis { int32_t lo, hi; float l, h; };            // lo / hi: LDS byte offsets (row * W * 16, column * 16)
+struct MapPrepRoi { uint32_t hdr[kMhWords]; MapAxis y[64]; MapAxis x[64]; };    // 256 + 2 x 1024 B
+static_assert(sizeof(MapPrepRoi) == 2304, "MapPrepRoi layout");
+
+__global__ __launch_bounds__(256) void map_prep_kernel(RoiAlignParams p, MapPrepRoi* __restrict__ prep) {
+  const int ri = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ri >= p.n_rois) return;
+  const RoiHead hd = roi_head_from_raw(p, load_roi_raw(p, ri));
+  MapPrepRoi* T = prep + ri;
+  const bool padrow = hd.lvl < 0 || hd.lvl >= p.n_levels;
+  const int H = p.lv[0].height, W = p.lv[0].width;
+  const int gh = hd.gh, gw = hd.gw;
+  const bool ytab = p.pooled_h * gh <= 64, xtab = p.pooled_w * gw <= 64;
+  if (!padrow) {
+    // entry e = (bin e / g, sample e % g) by lane e: (lane + .5) * (1 / g) truncated is exact (>= .5 / g away from an integer)
+    const int qy = (int)(((float)lane + 0.5f) * __frcp_rn((float)gh)), qx = (int)(((float)lane + 0.5f) * __frcp_rn((float)gw));
+    const AxisEntry ey = make_axis(hd.sh, hd.bin_h, min(qy, p.pooled_h - 1), lane - qy * gh, gh, H);
+    const AxisEntry ex = make_axis(hd.sw, hd.bin_w, min(qx, p.pooled_w - 1), lane - qx * gw, gw, W);
+    MapAxis ay; ay.lo = ey.lo * W * 16; ay.hi = ey.hi * W * 16; ay.l = ey.l; ay.h = ey.h;
+    MapAxis ax; ax.lo = ex.lo << 4; ax.hi = ex.hi << 4; ax.l = ex.l; ax.h = ex.h;
+    T->y[lane] = ay; T->x[lane] = ax;
+  }
+  const double rc = 1.0 / (double)hd.count;
+  uint32_t w = 0;
+  switch (lane) {
+    case kMhR: w = (uint32_t)hd.r; break;
+    case kMhB: w = (uint32_t)hd.b; break;
+    case kMhFlags: w = (padrow ? kMfPad : 0) | (ytab ? kMfYtab : 0) | (xtab ? kMfXtab : 0); break;
+    case kMhGh: w = (uint32_t)gh; break;
+    case kMhGw: w = (uint32_t)gw; break;
+    case kMhInv: w = __float_as_uint(hd.inv_count); break;
+    case kMhCount: w = __float_as_uint(hd.count); break;
+    case kMhRcpLo: w = (uint32_t)(__double_as_longlong(rc) & 0xffffffffll); break;
+    case kMhRcpHi: w = (uint32_t)((unsigned long long)__double_as_longlong(rc) >> 32); break;
+    case kMhSh: w = __float_as_uint(hd.sh); break;
+    case kMhSw: w = __float_as_uint(hd.sw); break;
+    case kMhBinH: w = __float_as_uint(hd.bin_h); break;
+    case kMhBinW: w = __float_as_uint(hd.bin_w); break;
+    default: break;
+  }
+  T->hdr[lane] = w;
+}
+
+struct MapRec { RoiRaw raw; uint32_t hw; MapAxis ay, ax; };       // what a wave holds of a RoI: its descriptor, or its prepared record
+
+template <typename TIn, typename TOut, int NQ, bool PREP>
 __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams p, int seg_len, int use_slab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int pend_idx[kMapWaves];
@@ -104,8 +157,14 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
   __syncthreads();
   int cur = -1;                               // image whose map is staged (uniform)
   int ri = -1;                                // the RoI this wave holds (taken from s_next; kept across a change of image)
-  RoiRaw raw;                                 // ... and its record
-  raw.d0 = raw.d1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  MapRec rec;                                 // ... and its record
+  rec.raw.d0 = rec.raw.d1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  rec.hw = 0; rec.ay.lo = rec.ay.hi = rec.ax.lo = rec.ax.hi = 0; rec.ay.l = rec.ay.h = rec.ax.l = rec.ax.h = 0.f;
+  const MapPrepRoi* __restrict__ prep = reinterpret_cast<const MapPrepRoi*>(p.prep);
+  auto fetch = [&](int i, MapRec& r) {         // three coalesced loads (prepared) or the 32-byte descriptor
+    if (PREP) { const MapPrepRoi* T = prep + i; r.hw = T->hdr[lane]; r.ay = T->y[lane]; r.ax = T->x[lane]; }
+    else r.raw = load_roi_raw(p, i);
+  };
   for (;;) {
     int want = -1;
     // ---- pool RoIs of the staged image; waves take them one by one (their cost varies 1 : 100 with the adaptive grid) -----
@@ -114,36 +173,60 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
         int t = 0;
         if (lane == 0) t = atomicAdd(&s_next, 1);
         ri = map_uni(t);
-        if (ri < r_end) raw = load_roi_raw(p, ri);
+        if (ri < r_end) fetch(ri, rec);
       }
       if (ri >= r_end) break;
-      const RoiHead hd = roi_head_from_raw(p, raw);
-      const bool padrow = hd.lvl < 0 || hd.lvl >= p.n_levels;
-      if (!padrow && hd.b != cur) { want = hd.b; break; }           // needs another image: keep the RoI, go to the rendezvous
+      // everything about the RoI is uniform across the wave: scalar registers, scalar loops
+      int hr, hb, gh, gw;
+      bool padrow, ytab, xtab;
+      float sh, sw, bin_h, bin_w, inv_count, count;
+      double rcp_count;
+      if (PREP) {
+        auto hw = [&](int k) { return (uint32_t)__builtin_amdgcn_readlane((int)rec.hw, k); };
+        const uint32_t fl = hw(kMhFlags);
+        hr = (int)hw(kMhR); hb = (int)hw(kMhB); gh = (int)hw(kMhGh); gw = (int)hw(kMhGw);
+        padrow = (fl & kMfPad) != 0; ytab = (fl & kMfYtab) != 0; xtab = (fl & kMfXtab) != 0;
+        sh = __uint_as_float(hw(kMhSh)); sw = __uint_as_float(hw(kMhSw)); bin_h = __uint_as_float(hw(kMhBinH)); bin_w = __uint_as_float(hw(kMhBinW));
+        inv_count = __uint_as_float(hw(kMhInv)); count = __uint_as_float(hw(kMhCount));
+        rcp_count = __longlong_as_double((long long)(((unsigned long long)hw(kMhRcpHi) << 32) | hw(kMhRcpLo)));
+      } else {
+        const RoiHead hd = roi_head_from_raw(p, rec.raw);
+        hr = hd.r; hb = hd.b; padrow = hd.lvl < 0 || hd.lvl >= p.n_levels;
+        gh = map_uni(hd.gh); gw = map_uni(hd.gw);
+        sh = __uint_as_float(map_uni(__float_as_uint(hd.sh))); sw = __uint_as_float(map_uni(__float_as_uint(hd.sw)));
+        bin_h = __uint_as_float(map_uni(__float_as_uint(hd.bin_h))); bin_w = __uint_as_float(map_uni(__float_as_uint(hd.bin_w)));
+        inv_count = hd.inv_count; count = hd.count;
+        rcp_count = 1.0 / (double)count;
+        // more than 64 entries per axis (a RoI of >= 10 x the pooled size): formed on the fly instead of once per RoI
+        ytab = p.pooled_h * gh <= 64; xtab = p.pooled_w * gw <= 64;
+      }
+      if (!padrow && hb != cur) { want = hb; break; }           // needs another image: keep the RoI, go to the rendezvous
       // take the NEXT RoI now: its record is in flight while this one is pooled
       int rn;
       { int t = 0; if (lane == 0) t = atomicAdd(&s_next, 1); rn = map_uni(t); }
-      RoiRaw rawn = raw;
-      if (rn < r_end) rawn = load_roi_raw(p, rn);
-      TOut* orow = out + ((size_t)hd.r * p.channels + c0) * bins;
+      MapRec recn = rec;
+      if (rn < r_end) fetch(rn, recn);
+      TOut* orow = out + ((size_t)hr * p.channels + c0) * bins;
       if (padrow) {                            // padding row of a fixed-shape batch: defined output
         for (int o = lane; o < nc * bins; o += 64) orow[o] = from_f32<TOut>(0.f);
-        ri = rn; raw = rawn;
+        ri = rn; rec = recn;
         continue;
       }
-      // everything about the RoI is uniform across the wave: scalar registers, scalar loops
-      const int gh = map_uni(hd.gh), gw = map_uni(hd.gw);
-      const float sh = __uint_as_float(map_uni(__float_as_uint(hd.sh))), sw = __uint_as_float(map_uni(__float_as_uint(hd.sw)));
-      const float bin_h = __uint_as_float(map_uni(__float_as_uint(hd.bin_h))), bin_w = __uint_as_float(map_uni(__float_as_uint(hd.bin_w)));
-      // Axis entries (roi_align_cpu_loop.cpp:36-95) are formed ONCE per RoI, entry e = (bin row e / gh, sample e % gh) by lane e,
-      // and fetched inside the sample loops with wave shuffles (ds_bpermute): no divisions, no float -> int in the loops.  More
-      // than 64 entries per axis (a RoI of >= 10 x the pooled size): formed on the fly instead.
-      const bool ytab = p.pooled_h * gh <= 64, xtab = p.pooled_w * gw <= 64;
-      // lane / g for the uniform small g: (lane + .5) * (1 / g) truncated is exact (the product is >= .5 / g away from an integer)
-      const int qy = (int)(((float)lane + 0.5f) * __frcp_rn((float)gh)), qx = (int)(((float)lane + 0.5f) * __frcp_rn((float)gw));
-      const AxisEntry ey = make_axis(sh, bin_h, min(qy, p.pooled_h - 1), lane - qy * gh, gh, H);
-      const AxisEntry ex = make_axis(sw, bin_w, min(qx, p.pooled_w - 1), lane - qx * gw, gw, W);
-      const int ey_lo = ey.lo * W * 16, ey_hi = ey.hi * W * 16, ex_lo = ex.lo << 4, ex_hi = ex.hi << 4;
+      // Axis entries (roi_align_cpu_loop.cpp:36-95) are formed ONCE per RoI, entry e = (bin row e / gh, sample e % gh) by lane e
+      // -- here, or by map_prep_kernel for all channel groups at once -- and fetched inside the sample loops with wave shuffles
+      // (ds_bpermute): no divisions, no float -> int in the loops.
+      int ey_lo, ey_hi, ex_lo, ex_hi;
+      AxisEntry ey, ex;
+      if (PREP) {
+        ey_lo = rec.ay.lo; ey_hi = rec.ay.hi; ey.l = rec.ay.l; ey.h = rec.ay.h;
+        ex_lo = rec.ax.lo; ex_hi = rec.ax.hi; ex.l = rec.ax.l; ex.h = rec.ax.h;
+      } else {
+        // lane / g for the uniform small g: (lane + .5) * (1 / g) truncated is exact (the product is >= .5 / g away from an integer)
+        const int qy = (int)(((float)lane + 0.5f) * __frcp_rn((float)gh)), qx = (int)(((float)lane + 0.5f) * __frcp_rn((float)gw));
+        ey = make_axis(sh, bin_h, min(qy, p.pooled_h - 1), lane - qy * gh, gh, H);
+        ex = make_axis(sw, bin_w, min(qx, p.pooled_w - 1), lane - qx * gw, gw, W);
+        ey_lo = ey.lo * W * 16; ey_hi = ey.hi * W * 16; ex_lo = ex.lo << 4; ex_hi = ex.hi << 4;
+      }
 #pragma unroll 1
       for (int b0 = 0; b0 < bins; b0 += 64) {
         const int bin = min(b0 + lane, bins - 1);        // lanes past the last bin repeat it (uniform control flow), never stored
@@ -182,8 +265,14 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
           res[4 * q + 0] = acc[q][0].x; res[4 * q + 1] = acc[q][0].y; res[4 * q + 2] = acc[q][1].x; res[4 * q + 3] = acc[q][1].y;
         }
 #pragma unroll
-        for (int c = 0; c < CG; c++)             // :216  output_val /= count
-          res[c] = hd.inv_count != 0.f ? res[c] * hd.inv_count : fdiv(res[c], hd.count);
+        for (int c = 0; c < CG; c++) {
+          // :216  output_val /= count.  count = gh * gw is a small integer: a power of two -> the product with its reciprocal is
+          // the quotient; otherwise float(double(x) * double(1 / count)) IS the correctly rounded float32 quotient -- x / count
+          // can never sit within 2^-33 (relative) of a rounding boundary of float32 (a 25-bit midpoint times an integer < 2^8
+          // is not a 24-bit number), while the double product is within 2^-52 of it -- at 3 instructions instead of the ~12 of
+          // an IEEE division (eight of them per RoI and channel group).
+          res[c] = inv_count != 0.f ? res[c] * inv_count : (float)((double)res[c] * rcp_count);
+        }
         if (use_slab) {
           // bins <= 64, whole channel quads: [CG][bins] is ONE contiguous run of the output -> wave-private slab, 16-byte stores
           if (on) {
@@ -202,7 +291,7 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
             if (c < nc) orow[(size_t)c * bins + bin] = from_f32<TOut>(res[c]);
         }
       }
-      ri = rn; raw = rawn;
+      ri = rn; rec = recn;
     }
     // ---- rendezvous: every wave has finished the staged image (or the run); the lowest waiting RoI names the next image ----
     if (lane == 0) { pend_idx[wv] = want >= 0 ? ri : 0x7fffffff; pend_img[wv] = want; }
@@ -296,8 +385,11 @@ static int launch_map_nq(const RoiAlignParams& p, int use_slab, hipStream_t stre
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_map<TIn, TOut, NQ>),
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_map<TIn, TOut, NQ, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMapLdsBytes);
+    if (attr_rc == hipSuccess)
+      attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_map<TIn, TOut, NQ, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kMapLdsBytes);
   });
   if (attr_rc != hipSuccess) return DTC_ELAUNCH;
   const int bins = p.pooled_h * p.pooled_w;
@@ -309,8 +401,16 @@ static int launch_map_nq(const RoiAlignParams& p, int use_slab, hipStream_t stre
   seg_len = ceil_div(seg_len, kMapWaves) * kMapWaves;
   n_seg = ceil_div(p.n_rois, seg_len);
   const size_t lds = (size_t)p.lv[0].height * p.lv[0].width * 16 * NQ + (use_slab ? (size_t)kMapWaves * 4 * NQ * bins * 4 : 0);
-  hipLaunchKernelGGL((roi_align_fwd_map<TIn, TOut, NQ>), dim3((unsigned)(ncg * n_seg)), dim3(kMapThreads), lds, stream, p,
-                     seg_len, use_slab);
+  if (p.prep) {
+    hipLaunchKernelGGL(map_prep_kernel, dim3((unsigned)ceil_div(p.n_rois, 4)), dim3(256), 0, stream, p,
+                       reinterpret_cast<MapPrepRoi*>(const_cast<void*>(p.prep)));
+    DTC_CHECK_LAUNCH();
+    hipLaunchKernelGGL((roi_align_fwd_map<TIn, TOut, NQ, true>), dim3((unsigned)(ncg * n_seg)), dim3(kMapThreads), lds, stream, p,
+                       seg_len, use_slab);
+  } else {
+    hipLaunchKernelGGL((roi_align_fwd_map<TIn, TOut, NQ, false>), dim3((unsigned)(ncg * n_seg)), dim3(kMapThreads), lds, stream, p,
+                       seg_len, use_slab);
+  }
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }
@@ -334,6 +434,18 @@ int launch_roi_align_map(const RoiAlignParams& p, int in_dtype, int out_dtype, h
   if (in_dtype == DTC_BF16 && out_dtype == DTC_BF16) return launch_map_t<bf16_t, bf16_t>(p, stream);
   if (in_dtype == DTC_F32 && out_dtype == DTC_BF16) return launch_map_t<float, bf16_t>(p, stream);
   return DTC_EUNSUPPORTED;
+}
+
+size_t roi_align_map_workspace_bytes(int n_rois) { return ((size_t)(n_rois > 0 ? n_rois : 1) * sizeof(MapPrepRoi) + 255) & ~(size_t)255; }
+
+int launch_roi_align_map_ws(const RoiAlignParams& p0, int in_dtype, int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  RoiAlignParams p = p0;
+  static const bool no_prep = [] { const char* e = getenv("DTC_RA_MAP_PREP"); return e && atoi(e) == 0; }();   // A/B knob
+  p.prep = nullptr;
+  if (workspace && !no_prep && workspace_bytes >= roi_align_map_workspace_bytes(p.n_rois) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
+      p.pooled_h <= 64 && p.pooled_w <= 64 && (long long)p.lv[0].height * p.lv[0].width * 16 < (1ll << 30))
+    p.prep = workspace;
+  return launch_roi_align_map(p, in_dtype, out_dtype, stream);
 }
 
 }  // namespace dtc

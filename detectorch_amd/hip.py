@@ -80,6 +80,10 @@ def lib():
     L.dtc_fpn_collect_distribute.argtypes = [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p, i, p]
     L.dtc_roi_align_forward_packed.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, i, i, i, p, i, p]
     L.dtc_roi_align_forward_packed.restype = i
+    L.dtc_roi_align_workspace_bytes.argtypes = [i]
+    L.dtc_roi_align_workspace_bytes.restype = C.c_size_t
+    L.dtc_roi_align_forward_packed_ws.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, i, i, i, p, i, p, C.c_size_t, p]
+    L.dtc_roi_align_forward_packed_ws.restype = i
     L.dtc_fpn_collect_distribute.restype = i
     L.dtc_postprocess_detections_workspace_bytes.argtypes = [i, i, i]
     L.dtc_postprocess_detections_workspace_bytes.restype = sz

@@ -256,6 +256,7 @@ class C4RegionPath:
         self.rois_by_level, self.level_counts, self.idx_restore = e(B, T, 4), e(B, 1, dtype=i32), e(B, T, dtype=i32)
         self.roi_order, self.roi_desc = e(B, T, dtype=i32), e(B, T, 8)
         self.box_feats = e(B * T, self.C, pooled, pooled, dtype=feat_dtype)
+        self.ra_ws = hip.workspace(L.dtc_roi_align_workspace_bytes(B * T), dev)
         D = max_out
         self.dets, self.det_roi = torch.zeros((B, D, 6), device=dev), torch.zeros((B, D), dtype=i32, device=dev)
         self.det_scaled, self.det_count = torch.zeros((B, D, 4), device=dev), e(B, dtype=i32)
@@ -298,9 +299,11 @@ class C4RegionPath:
 
     def _roi_align_box(self, st=None):
         st = st or hip.stream_ptr(self.dev)
-        hip.check(hip.lib().dtc_roi_align_forward_packed(self.feat_lv, 1, self.C, self.feat_code, self.roi_desc.data_ptr(),
-                                                  self.B * self.top_n, self.pooled, self.pooled, self.sr,
-                                                  self.box_feats.data_ptr(), self.out_code, st), "roi_align(c4)")
+        # (workspace: the per-RoI records the map-stationary kernel's preparation pass writes, csrc/roi_align_map.hip)
+        hip.check(hip.lib().dtc_roi_align_forward_packed_ws(self.feat_lv, 1, self.C, self.feat_code, self.roi_desc.data_ptr(),
+                                                     self.B * self.top_n, self.pooled, self.pooled, self.sr,
+                                                     self.box_feats.data_ptr(), self.out_code, self.ra_ws.data_ptr(),
+                                                     self.ra_ws.numel(), st), "roi_align(c4)")
 
     step = FpnRegionPath.step
 

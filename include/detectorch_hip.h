@@ -83,6 +83,16 @@ int dtc_roi_align_forward_packed(const dtc_feat_level* levels, int n_levels, int
                                  const float* roi_desc, int n_rois, int pooled_h, int pooled_w, int sampling_ratio, void* out,
                                  int out_dtype, dtc_stream_t stream);
 
+/* dtc_roi_align_forward_packed with a caller-owned workspace (dtc_roi_align_workspace_bytes(n_rois) bytes, 16-byte aligned):
+ * lets the map-stationary kernel (the C4 heads) form everything about a RoI that does not depend on the channels -- scaled box,
+ * bin sizes, adaptive grid, the axis samples of lib/cppcuda_cffi/src/cpp/roi_align_cpu_loop.cpp:36-95 -- ONCE per launch in a
+ * preparation kernel instead of once per (RoI, 8-channel workgroup).  Same results bit for bit; configurations that do not
+ * take that kernel ignore the workspace (NULL is allowed: then this IS dtc_roi_align_forward_packed). */
+size_t dtc_roi_align_workspace_bytes(int n_rois);
+int dtc_roi_align_forward_packed_ws(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,
+                                    const float* roi_desc, int n_rois, int pooled_h, int pooled_w, int sampling_ratio, void* out,
+                                    int out_dtype, void* workspace, size_t workspace_bytes, dtc_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * A5  Hard NMS
  * --------------------------------------------------------------------------------------------------------------- */

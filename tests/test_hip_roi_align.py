@@ -236,6 +236,13 @@ def test_map_stationary_kernel_vs_oracle(hip, oracle, case):
     assert not res[n:].any()
     assert np.abs(res[:n] - ref).max() <= TOL
     assert np.array_equal(res[:n], ref)
+    # the same launch with the per-launch preparation pass (dtc_roi_align_forward_packed_ws: geometry and axis samples formed
+    # once per RoI by map_prep_kernel instead of once per 8-channel workgroup): bit-identical
+    ws = hip.workspace(hip.lib().dtc_roi_align_workspace_bytes(n + 5), "cuda")
+    out2 = torch.full((n + 5, C, ph, pw), 5.0, device="cuda")
+    rc = hip.lib().dtc_roi_align_forward_packed_ws(lvs, 1, ch, hip._dtype_code(dt), cu(desc).data_ptr(), n + 5, ph, pw, sr,
+                                                   out2.data_ptr(), 0, ws.data_ptr(), ws.numel(), hip.stream_ptr())
+    assert rc == 0 and torch.equal(out2, out)
 
 
 _VARIANT_CHILD = r"""
