@@ -19,6 +19,7 @@ Differences from the reference:
   * `head_dtype=torch.bfloat16`: RoIAlign writes the pooled features in bf16 and fc6/fc7 run as bf16 MFMA GEMMs;
   * inference only (the reference's README.md:3 scope).
 """
+import contextlib
 import pickle
 from math import log2
 
@@ -215,10 +216,14 @@ class detector(nn.Module):
                  use_mask_head=False, mask_head_type='upshare', roi_feature_channels=2048, N_classes=81,
                  detector_pkl_file=None, base_cnn_pkl_file=None, output_prob=True, roi_height=14, roi_width=14,
                  roi_spatial_scale=0.0625, roi_sampling_ratio=0, channels_last=False, fuse_rpn_sigmoid=True,
-                 head_dtype=None):
+                 head_dtype=None, backbone_dtype=None):
         super().__init__()
         self.fuse_rpn_sigmoid = bool(fuse_rpn_sigmoid)   # extension: RPN sigmoid folded into the top-k kernel (same outputs)
         self.head_dtype = head_dtype    # extension: torch.bfloat16 / float16 -> pooled features + fc6/fc7 in that dtype (MFMA GEMMs)
+        # extension (forward_batched): torch.bfloat16 / float16 -> ResNet / FPN / RPN-head convs under autocast in that dtype;
+        # the feature maps reach RoIAlign as 16-bit tensors (half the bytes per staged line) and, with head_dtype set to the same
+        # type, the pooled features reach fc6 without a cast.  The RPN outputs are widened to float32 for the proposal kernels.
+        self.backbone_dtype = backbone_dtype
         self.N_classes = N_classes
         self._paths = {}               # (B, padded h, padded w, device) -> FpnRegionPath, least recently used first
         self.max_cached_paths = 4
@@ -373,12 +378,19 @@ class detector(nn.Module):
         dev = images.device
         if self.channels_last:
             images = images.contiguous(memory_format=torch.channels_last)
-        img_features = self.conv_body(images)
-        feats = list(img_features)
-        rpn_in = feats + ([F.max_pool2d(feats[-1], 1, stride=2)] if self.fpn_extra_lvl else [])
-        cls_bbox = [self.rpn(f, logits=self.fuse_rpn_sigmoid) for f in rpn_in]
+        low = self.backbone_dtype is not None and self.backbone_dtype != torch.float32
+        if low and self.head_dtype not in (None, torch.float32, self.backbone_dtype):
+            raise ValueError("backbone_dtype and head_dtype must be the same 16-bit type (RoIAlign does not mix fp16 and bf16)")
+        with (torch.autocast("cuda", dtype=self.backbone_dtype) if low else contextlib.nullcontext()):
+            img_features = self.conv_body(images)
+            feats = list(img_features)
+            rpn_in = feats + ([F.max_pool2d(feats[-1], 1, stride=2)] if self.fpn_extra_lvl else [])
+            cls_bbox = [self.rpn(f, logits=self.fuse_rpn_sigmoid) for f in rpn_in]
+        if low:      # every level in the autocast type (a level left in float32 by an op outside autocast's list would mix dtypes)
+            feats = [f.to(self.backbone_dtype) for f in feats]
+            img_features = feats
         path = self._region_path(B, h, w, dev)
-        path.bind_rpn([c.contiguous() for c, _ in cls_bbox], [b.contiguous() for _, b in cls_bbox], feats,
+        path.bind_rpn([c.float().contiguous() for c, _ in cls_bbox], [b.float().contiguous() for _, b in cls_bbox], feats,
                       scores_are_logits=self.fuse_rpn_sigmoid)
         path.launch_proposals()
         x = self._head(path.box_feats)                                              # [B*1000, 1024]
@@ -392,8 +404,13 @@ class detector(nn.Module):
         path.img_features, path.cls_logits_out, path.bbox_pred_out = img_features, cls_logits, bbox_pred
         if self.use_mask_head:
             mh = self.mask_head
-            m = mh.conv_head(path.mask_feats.float() if path.mask_feats.dtype != torch.float32 else path.mask_feats)
-            m = mh.classif_logits(mh.relu(mh.transposed_conv(m)))
+            if self.head_dtype is not None and self.head_dtype != torch.float32:    # mask-head convs in the pooled features' type
+                with torch.autocast("cuda", dtype=self.head_dtype):
+                    m = mh.classif_logits(mh.relu(mh.transposed_conv(mh.conv_head(path.mask_feats.to(self.head_dtype)))))
+                m = m.float()
+            else:
+                m = mh.conv_head(path.mask_feats.float() if path.mask_feats.dtype != torch.float32 else path.mask_feats)
+                m = mh.classif_logits(mh.relu(mh.transposed_conv(m)))
             path.bind_masks(torch.sigmoid(m).contiguous())                          # [B*128, 81, 28, 28]
             path.launch_masks()
         return path

@@ -149,3 +149,26 @@ def test_forward_batched_batch2_and_bf16_head():
     assert float(ok.float().mean()) > 0.9
     err = (pb.cls_logits_out[0, :nb][ok] - ref_logits[0][j[ok]]).abs().max() / ref_logits.abs().max()
     assert float(err) < 5e-2
+
+
+def test_forward_batched_bf16_backbone_feeds_roialign_and_heads_without_a_cast():
+    """SURVEY 8f-2 remainder: backbone_dtype = head_dtype = bfloat16 -- ResNet / FPN / RPN convs under bf16 autocast, the bf16
+    feature maps go straight into RoIAlign (fp32 accumulate), the pooled bf16 features straight into fc6.  The region path on
+    those maps is exact: its bf16 output is the fp32-output launch of the same descriptors rounded once."""
+    from detectorch_amd import hip
+    model = _boost(_fpn_model())
+    model.backbone_dtype = model.head_dtype = torch.bfloat16
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    images = torch.randn(2, 3, 320, 448, generator=g, device="cuda")
+    sf, im_size = torch.tensor([1.6, 1.6], device="cuda"), torch.tensor([[200.0, 280.0], [200.0, 280.0]], device="cuda")
+    p = model.forward_batched(images, sf, im_size)
+    torch.cuda.synchronize()
+    assert all(f.dtype == torch.bfloat16 for f in p.feats) and p.box_feats.dtype == torch.bfloat16
+    assert p.rpn_cls[0].dtype == torch.float32 and min(p.det_count.tolist()) > 0
+    assert bool(torch.isfinite(p.cls_logits_out).all()) and bool(torch.isfinite(p.dets).all())
+    R = p.B * p.top_n
+    out32 = torch.empty((R, p.C, 7, 7), dtype=torch.float32, device="cuda")
+    hip.check(hip.lib().dtc_roi_align_forward_packed(p.feat_lv, 4, p.C, hip.DTC_BF16, p.roi_desc.data_ptr(), R, 7, 7, 2,
+                                                     out32.data_ptr(), hip.DTC_F32, hip.stream_ptr()), "packed bf16 -> fp32")
+    torch.cuda.synchronize()
+    assert torch.equal(out32.to(torch.bfloat16), p.box_feats)

@@ -32,6 +32,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--batched", action="store_true", help="time detector.forward_batched (backbone -> fused region path -> heads -> detections -> masks, one launch chain, no host round trip) instead of the reference-shaped per-image flow")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "fp16"], default="fp32", help="--batched: backbone_dtype = head_dtype")
     a = ap.parse_args()
     from detectorch_amd.model.detector import detector
     from detectorch_amd.utils import result_utils
@@ -43,6 +46,28 @@ def main():
                  use_rpn_head=True, use_mask_head=True, mask_head_type='1up4convs', channels_last=a.channels_last).cuda()
     if a.channels_last:
         m = m.to(memory_format=torch.channels_last)
+    if a.batched:
+        dt = {"fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[a.dtype]
+        m.backbone_dtype = m.head_dtype = dt
+        m.classif_head.weight.data *= 60.0                                  # random weights: make some detections exist
+        images = torch.randn(a.batch, 3, 800, 1344, device="cuda")
+        sfb = torch.full((a.batch,), 1.6, device="cuda")
+        szb = torch.tensor([[500.0, 833.0]] * a.batch, device="cuda")
+        with torch.no_grad():
+            low = torch.autocast("cuda", dtype=dt) if dt is not None else None
+            def body():
+                if low is None:
+                    return m.conv_body(images)
+                with torch.autocast("cuda", dtype=dt):
+                    return m.conv_body(images)
+            t_body, _ = timed(body, a.iters)
+            t_all, path = timed(lambda: m.forward_batched(images, sfb, szb), a.iters)
+        print({"mode": "forward_batched", "batch": a.batch, "dtype": a.dtype, "layout": "NHWC" if a.channels_last else "NCHW",
+               "backbone_fpn_ms": round(t_body, 3), "forward_batched_ms": round(t_all, 3),
+               "ms_per_image": round(t_all / a.batch, 3), "images_per_sec": round(a.batch / t_all * 1e3, 1),
+               "not_backbone_ms_per_image": round((t_all - t_body) / a.batch, 3),
+               "detections": path.det_count.tolist()})
+        return
     image = torch.randn(1, 3, 800, 1344, device="cuda")
     sf = torch.tensor([1.6], device="cuda")
     im_size = torch.tensor([500.0, 833.0, 3.0])
