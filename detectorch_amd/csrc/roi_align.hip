@@ -355,7 +355,7 @@ __device__ __forceinline__ void run_passes(Stager& st, LdsGeom& G, const dtc_fea
 }
 
 #ifndef DTC_RA_WAVES
-#define DTC_RA_WAVES 3
+#define DTC_RA_WAVES 2
 #endif
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(kRoiAlignThreads, DTC_RA_WAVES) void roi_align_fwd_lds(RoiAlignParams p, int lds_floats) {
