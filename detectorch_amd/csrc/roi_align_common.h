@@ -122,4 +122,8 @@ int launch_roi_align_map(const RoiAlignParams& p, int in_dtype, int out_dtype, h
 size_t roi_align_map_workspace_bytes(int n_rois);      // per-launch preparation records (optional: workspace == nullptr -> none)
 int launch_roi_align_map_ws(const RoiAlignParams& p, int in_dtype, int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
+// launchers of the channels_last kernel with an LDS-DMA staged window (roi_align_nhwc.hip): sampling_ratio 2, <= 64 bins
+bool roi_align_nhwc_lds_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
+int launch_roi_align_nhwc_lds(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream);
+
 }  // namespace dtc

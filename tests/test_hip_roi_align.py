@@ -378,3 +378,86 @@ def test_c4_true_shape_vs_reference_compiled(hip, oracle):
     out = hip.roi_align_forward(cu(feat), 1 / 16., cu(rois5), 14, 14, 0).cpu().numpy()
     assert np.abs(out - ref).max() <= TOL
     assert np.array_equal(out, ref)
+
+
+# ---- channels_last maps: the LDS-DMA staged kernel (csrc/roi_align_nhwc.hip) -------------------------------------------------------
+def _nhwc_case(oracle, C, seed, R=260):
+    rs = synth.rng(11, seed)
+    shapes = synth.fpn_level_shapes()[:4]
+    feats = [synth.make_features(rs, (2, C, h, w)) - 0.3 for (h, w) in shapes]
+    small = synth.make_rois(rs, R - 60, max_side=90.0)
+    big = synth.make_rois(rs, 52, max_side=900.0)
+    odd = np.array([[0, 0, 1343, 799], [-40, -30, 25, 20], [1300, 770, 1500, 900], [100, 100, 90, 90], [0, 0, 0, 0],
+                    [1343, 799, 1343, 799], [0, 300, 1343, 330], [600, 0, 640, 799]], np.float32)
+    rois = np.vstack([small, big, odd]).astype(np.float32)
+    lv = (oracle.map_rois_to_fpn_levels(rois, 2, 5) - 2).astype(np.int32)
+    lv[-8:] = [0, 0, 3, 1, 2, 3, 0, 0]           # the whole image / full-width / full-height boxes on the FINEST level: no strip fits
+    rois5 = np.hstack([rs.randint(0, 2, (rois.shape[0], 1)).astype(np.float32), rois]).astype(np.float32)
+    return feats, rois5, lv
+
+
+@pytest.mark.parametrize("dtype,C", [("f32", 64), ("f32", 256), ("f16", 128), ("bf16", 256)])
+def test_nhwc_lds_dma_kernel_vs_oracle(hip, oracle, dtype, C):
+    """channels_last feature maps, 7x7 bins, sampling ratio 2: window staged with LDS-DMA, lane <-> channel chunk.  Small boxes
+    (one strip), large ones (several strips of bin rows), boxes no strip fits (per-bin-row straight from global), every border case,
+    the 42-column P5 map; float32 maps take the new kernel, 16-bit maps the direct-gather kernel by default (the new one in the
+    child-process test below): bit-exact against the oracle on the up-cast maps, and the 16-bit outputs are that result rounded once."""
+    feats, rois5, lv = _nhwc_case(oracle, C, C + len(dtype))
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    tf = [cu(f).to(tdt).contiguous(memory_format=torch.channels_last) for f in feats]
+    up = [t.float().contiguous().cpu().numpy() for t in tf]
+    ref = np.zeros((rois5.shape[0], C, 7, 7), np.float32)
+    for l in range(4):
+        m = lv == l
+        if m.any():
+            ref[m] = oracle.roi_align_forward(up[l], rois5[m], 7, 7, synth.FPN_ROI_SCALES[l], 2)
+    out = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, cu(rois5), 7, 7, 2, roi_levels=cu(lv))
+    assert out.dtype == torch.float32 and np.array_equal(out.cpu().numpy(), ref)
+    if dtype != "f32":
+        o16 = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, cu(rois5), 7, 7, 2, roi_levels=cu(lv), out_dtype=tdt)
+        assert torch.equal(o16.cpu(), torch.from_numpy(ref).to(tdt))
+    # the same maps in NCHW through the cluster-stationary kernel: the two layouts agree bit for bit
+    nchw = hip.roi_align_forward([t.contiguous() for t in tf], synth.FPN_ROI_SCALES, cu(rois5), 7, 7, 2, roi_levels=cu(lv))
+    assert torch.equal(nchw, out)
+
+
+_NHWC_CHILD = r"""
+import sys, os, numpy as np, torch
+root = %r
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle")); sys.path.insert(0, os.path.join(root, "tests"))
+import oracle as orc
+from detectorch_amd import hip, synth
+import test_hip_roi_align as T
+for tdt, C in ((torch.float32, 64),) + (((torch.float16, 128), (torch.bfloat16, 256)) if os.environ.get("DTC_RA_NHWC_LDS_16BIT") else ()):
+    feats, rois5, lv = T._nhwc_case(orc, C, 5)
+    tf = [T.cu(f).to(tdt).contiguous(memory_format=torch.channels_last) for f in feats]
+    up = [t.float().contiguous().cpu().numpy() for t in tf]
+    ref = np.zeros((rois5.shape[0], C, 7, 7), np.float32)
+    for l in range(4):
+        m = lv == l
+        if m.any():
+            ref[m] = orc.roi_align_forward(up[l], rois5[m], 7, 7, synth.FPN_ROI_SCALES[l], 2)
+    out = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, T.cu(rois5), 7, 7, 2, roi_levels=T.cu(lv)).cpu().numpy()
+    assert np.array_equal(out, ref), str(tdt)
+    if tdt != torch.float32:
+        o16 = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, T.cu(rois5), 7, 7, 2, roi_levels=T.cu(lv), out_dtype=tdt)
+        assert torch.equal(o16.cpu(), torch.from_numpy(ref).to(tdt))
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("env", ["DTC_RA_NHWC_LDS_KB=24", "DTC_RA_NHWC_LDS_KB=78", "DTC_RA_NHWC_LDS_KB=156", "DTC_RA_NHWC_LDS=0",
+                                 "DTC_RA_NHWC_LDS_16BIT=1", "DTC_RA_NHWC_LDS_16BIT=1 DTC_RA_NHWC_LDS_KB=24"])
+def test_nhwc_lds_image_sizes_in_child_process(hip, oracle, env):
+    """The LDS image size decides how many strips a window takes (24 KB: nearly every RoI in several strips or straight from
+    global; 156 KB: one workgroup per CU, one strip) -- and must not change a bit; DTC_RA_NHWC_LDS=0 is the direct-gather kernel."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for kv in env.split():
+        k, v = kv.split("=")
+        e[k] = v
+    r = subprocess.run([sys.executable, "-c", _NHWC_CHILD % root], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, env + "\n" + r.stdout[-1500:] + r.stderr[-3000:]
