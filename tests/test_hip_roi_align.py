@@ -268,13 +268,21 @@ for (C, ph, sr, R, seed) in [(32, 7, 2, 200, 5), (130, 7, 2, 60, 6), (24, 14, 2,
             ref16[m] = orc.roi_align_forward(h16[l].float().cpu().numpy(), rois5[m], ph, ph, synth.FPN_ROI_SCALES[l], sr)
     out16 = hip.roi_align_forward(h16, synth.FPN_ROI_SCALES, T.cu(rois5), ph, ph, sr, roi_levels=T.cu(lv)).cpu().numpy()
     assert np.array_equal(out16, ref16), ("fp16", C, ph, sr)
+    # the (image, level, row band, x) visiting order of dtc_fpn_collect_distribute: neighbours overlap, clusters merge
+    yc, xc = (rois5[:, 2] + rois5[:, 4]) * 0.5, (rois5[:, 1] + rois5[:, 3]) * 0.5
+    band = (yc / (4 * 2 ** lv.astype(np.float32) * 16)).astype(np.int32)
+    order = np.lexsort((xc, band, lv, rois5[:, 0]))
+    outs = hip.roi_align_forward([T.cu(f) for f in feats], synth.FPN_ROI_SCALES, T.cu(rois5[order]), ph, ph, sr,
+                                 roi_levels=T.cu(lv[order])).cpu().numpy()
+    assert np.array_equal(outs, ref[order]), ("visiting order", C, ph, sr)
 print("ok")
 """
 
 
 @pytest.mark.parametrize("env", ["DTC_ROIALIGN_TILE=0", "DTC_ROIALIGN_GENERAL=1", "DTC_ROIALIGN_TILE=0 DTC_RA_NO_CTS64=1",
                                  "DTC_ROIALIGN_MAP=0",
-                                 "DTC_ROIALIGN_NO_NHWC_DIRECT=1", "DTC_RA_TILE_CHBLOCK=128", "DTC_RA_TILE_CHBLOCK=32"])
+                                 "DTC_ROIALIGN_NO_NHWC_DIRECT=1", "DTC_RA_TILE_CHBLOCK=128", "DTC_RA_TILE_CHBLOCK=32",
+                                 "DTC_RA_TILE_DMA=1", "DTC_RA_TILE_DMA=1 DTC_RA_TILE_LDS_KB=40", "DTC_RA_TILE_DMA=1 DTC_RA_TILE_LDS_KB=104 DTC_RA_TILE_NQCAP=4"])
 def test_kernel_variants_bit_exact_in_child_process(hip, oracle, env):
     """Every RoIAlign kernel that stays in the library -- the cluster-stationary default in its three workgroup shapes, the
     RoI-stationary LDS kernel with its stager options, the channels_last direct kernel, the per-output gather kernel -- does
