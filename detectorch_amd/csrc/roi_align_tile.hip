@@ -34,6 +34,7 @@
 // the LDS image is gathered per output straight from global memory; padding rows (level < 0) are zero-filled.
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 
@@ -113,10 +114,22 @@ struct TileTrace {};
 // LDS slot (16-byte units: one pixel x 4 channels) of window pixel px inside one quad image: one pad slot every 8 pixels
 __device__ __forceinline__ int tile_phys(int px) { return px + (px >> 3); }
 
-// Everything a lane needs to pool ITS (RoI, bin) from the LDS image, formed once per cluster.
+// Everything a lane needs to pool ITS (RoI, bin) from the LDS image, formed once per cluster.  Two forms, chosen per wavefront:
+//  * exact (mode 0): the reference's 2 x 2 samples x 4 taps, a[(iy * 2 + ix) * 4 + tap] = LDS byte offset (inside a quad image) of
+//    (y.lo,x.lo) (y.lo,x.hi) (y.hi,x.lo) (y.hi,x.hi), w = {yl0, yl1, yh0, yh1, xl0, xl1, xh0, xh1}: the same float32 operations
+//    in the same order as roi_align_cpu_loop.cpp:203-216 -- bit-identical results;
+//  * merged (mode 3 / 4): the 16 taps of a bin fall on the (y1.hi - y0.lo + 1) x (x1.hi - x0.lo + 1) pixels between its first and
+//    last sample -- 3 x 3 or fewer when the bin is at most 2 pixels wide, which is 3 of 4 RoIs of the FPN box head -- and bilinear
+//    weights are products of a row and a column factor, so  sum_samples sum_taps w v = sum_r Wy[r] sum_c Wx[c] v[r][c]  with
+//    Wy / Wx the per-row / per-column sums of the axis weights: 9 (mode 3) or 16 (mode 4) distinct LDS reads and 24 / 40 packed
+//    FMAs per channel quad instead of 16 reads, 16 weight products and 64 packed multiplies / adds.  a[r * 4 + c] = offset of
+//    pixel (row min(r, rows - 1), column min(c, columns - 1)) of that neighbourhood (the clamped copies carry weight 0),
+//    w = {Wy0..3, Wx0..3}.  Same real-number result, different rounding: within a few float32 ulps of the reference (the
+//    contract is 1e-4), NOT bit-identical -- dtc_roi_align_set_exact(1) / DTC_RA_EXACT=1 selects mode 0 everywhere.
 struct TileItem {
-  int a[2][2][4];           // [iy][ix][tap]: LDS byte offsets (inside a quad image) of (y.lo,x.lo) (y.lo,x.hi) (y.hi,x.lo) (y.hi,x.hi)
-  float yl[2], yh[2], xl[2], xh[2];
+  int a[16];
+  float w[8];
+  int mode;                 // wave-uniform: 0, 3, 4
   bool on;
 };
 
@@ -171,8 +184,50 @@ __device__ __forceinline__ void tile_store_slab(const RoiAlignParams& p, const T
   }
 }
 
+__device__ __forceinline__ f32x2 pk_fma(float a, f32x2 b, f32x2 c) {
+  const f32x2 av = {a, a};
+  return __builtin_elementwise_fma(av, b, c);          // v_pk_fma_f32
+}
+
+// merged-tap pooling of one quad image: ROWS x COLS pixels, row factors Wy = w[0..3], column factors Wx = w[4..7]
+template <int ROWS, int COLS>
+__device__ __forceinline__ void tile_pool_merged_quad(const char* wq, const TileItem& it, float* o, int bins) {
+  f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+  constexpr int RB = ROWS * COLS <= 9 ? ROWS : 2;       // rows whose taps are in flight together (<= 9 x 4 registers)
+#pragma unroll
+  for (int r0 = 0; r0 < ROWS; r0 += RB) {
+    f32x4 t[RB][COLS];
+#pragma unroll
+    for (int r = 0; r < RB; r++)
+#pragma unroll
+      for (int c = 0; c < COLS; c++)
+        t[r][c] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(wq + it.a[(r0 + r) * 4 + c], 16));
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      f32x2 s01 = it.w[4] * t[r][0].lo, s23 = it.w[4] * t[r][0].hi;
+#pragma unroll
+      for (int c = 1; c < COLS; c++) { s01 = pk_fma(it.w[4 + c], t[r][c].lo, s01); s23 = pk_fma(it.w[4 + c], t[r][c].hi, s23); }
+      a01 = pk_fma(it.w[r0 + r], s01, a01);
+      a23 = pk_fma(it.w[r0 + r], s23, a23);
+    }
+    if (RB < ROWS) __builtin_amdgcn_sched_barrier(0);
+  }
+  const float a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
+  o[0] = a0 * 0.25f; o[bins] = a1 * 0.25f; o[2 * bins] = a2 * 0.25f; o[3 * bins] = a3 * 0.25f;
+}
+
 // The lane's (RoI, bin) pooled from nq quad images (img: the first one, plane_bytes apart) into its slab column `so`.
 __device__ __forceinline__ void tile_pool(const char* img, int plane_bytes, const TileItem& it, float* so, int bins, int nq) {
+  if (it.mode == 3) {
+#pragma unroll 1
+    for (int q = 0; q < nq; q++) tile_pool_merged_quad<3, 3>(img + uni(q * plane_bytes), it, so + uni(4 * q * bins), bins);
+    return;
+  }
+  if (it.mode == 4) {
+#pragma unroll 1
+    for (int q = 0; q < nq; q++) tile_pool_merged_quad<4, 4>(img + uni(q * plane_bytes), it, so + uni(4 * q * bins), bins);
+    return;
+  }
 #pragma unroll 1
   for (int q = 0; q < nq; q++) {
     // uniform quad offset, opaque to the optimiser: otherwise every tap address becomes its own induction variable
@@ -187,11 +242,11 @@ __device__ __forceinline__ void tile_pool(const char* img, int plane_bytes, cons
       for (int ix = 0; ix < 2; ix++)
 #pragma unroll
         for (int k = 0; k < 4; k++)                                       // 8 ds_read_b128 in flight per sample row
-          t[ix][k] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(wq + it.a[iy][ix][k], 16));
+          t[ix][k] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(wq + it.a[(iy * 2 + ix) * 4 + k], 16));
 #pragma unroll
       for (int ix = 0; ix < 2; ix++) {
-        const float w1 = it.yh[iy] * it.xh[ix], w2 = it.yh[iy] * it.xl[ix];               // roi_align_cpu_loop.cpp:95
-        const float w3 = it.yl[iy] * it.xh[ix], w4 = it.yl[iy] * it.xl[ix];
+        const float yl = it.w[iy], yh = it.w[2 + iy], xl = it.w[4 + ix], xh = it.w[6 + ix];
+        const float w1 = yh * xh, w2 = yh * xl, w3 = yl * xh, w4 = yl * xl;                      // roi_align_cpu_loop.cpp:95
         a01 += w1 * t[ix][0].lo + w2 * t[ix][1].lo + w3 * t[ix][2].lo + w4 * t[ix][3].lo;    // :208-211
         a23 += w1 * t[ix][0].hi + w2 * t[ix][1].hi + w3 * t[ix][2].hi + w4 * t[ix][3].hi;
       }
@@ -582,25 +637,51 @@ __global__ __launch_bounds__(NT, DMA ? TileShape<NT>::kWavesDma : TileShape<NT>:
     const int rl = itx / bins, bin = itx - rl * bins;
     const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
     const TileRoi hd = troi[first + rl];     // sh / sw / bin sizes as phase A formed them
-    int ylo[2], yhi[2], xlo[2], xhi[2];      // window-relative: rows premultiplied by the window width
+    AxisEntry ey[2], ex[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      const AxisEntry ey = make_axis(hd.sh, hd.bin_h, ph, i, 2, L.height);
-      const AxisEntry ex = make_axis(hd.sw, hd.bin_w, pw, i, 2, L.width);
-      it.yl[i] = ey.l; it.yh[i] = ey.h; it.xl[i] = ex.l; it.xh[i] = ex.h;
-      ylo[i] = (ey.lo - gy0) * tw; yhi[i] = (ey.hi - gy0) * tw;
-      xlo[i] = ex.lo - g.x0a; xhi[i] = ex.hi - g.x0a;
+      ey[i] = make_axis(hd.sh, hd.bin_h, ph, i, 2, L.height);
+      ex[i] = make_axis(hd.sw, hd.bin_w, pw, i, 2, L.width);
     }
+    // window-relative slot of pixel (row y, column x) of the level
+    auto slot = [&](int y, int x) {
+      const int px = (y - gy0) * tw + (x - g.x0a);
+      return (g.mode == kStageDma ? px : tile_phys(px)) << 4;            // DMA image: linear
+    };
+    // pooling form of this wavefront: merged taps when the neighbourhood of every lane is at most 3 x 3 / 4 x 4 pixels
+    const int yext = ey[1].hi - ey[0].lo, xext = ex[1].hi - ex[0].lo;     // rows - 1, columns - 1 (positions are non-decreasing)
+    const unsigned long long all = __builtin_amdgcn_ballot_w64(true);
+    const bool fit3 = __builtin_amdgcn_ballot_w64(yext <= 2 && xext <= 2) == all;
+    const bool fit4 = __builtin_amdgcn_ballot_w64(yext <= 3 && xext <= 3) == all;
+    it.mode = (reverse & 4) ? 0 : fit3 ? 3 : fit4 ? 4 : 0;
+    if (it.mode == 0) {
 #pragma unroll
-    for (int iy = 0; iy < 2; iy++)
+      for (int iy = 0; iy < 2; iy++)
 #pragma unroll
-      for (int ix = 0; ix < 2; ix++) {
-        int t0 = ylo[iy] + xlo[ix], t1 = ylo[iy] + xhi[ix], t2 = yhi[iy] + xlo[ix], t3 = yhi[iy] + xhi[ix];
-        if (g.mode != kStageDma) { t0 = tile_phys(t0); t1 = tile_phys(t1); t2 = tile_phys(t2); t3 = tile_phys(t3); }   // DMA image: linear
-        t0 <<= 4; t1 <<= 4; t2 <<= 4; t3 <<= 4;
-        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));   // one finished VGPR per tap: do not re-derive in the loop
-        it.a[iy][ix][0] = t0; it.a[iy][ix][1] = t1; it.a[iy][ix][2] = t2; it.a[iy][ix][3] = t3;
+        for (int ix = 0; ix < 2; ix++) {
+          int t0 = slot(ey[iy].lo, ex[ix].lo), t1 = slot(ey[iy].lo, ex[ix].hi), t2 = slot(ey[iy].hi, ex[ix].lo), t3 = slot(ey[iy].hi, ex[ix].hi);
+          asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));   // one finished VGPR per tap: do not re-derive in the loop
+          const int k = (iy * 2 + ix) * 4;
+          it.a[k] = t0; it.a[k + 1] = t1; it.a[k + 2] = t2; it.a[k + 3] = t3;
+        }
+      it.w[0] = ey[0].l; it.w[1] = ey[1].l; it.w[2] = ey[0].h; it.w[3] = ey[1].h;
+      it.w[4] = ex[0].l; it.w[5] = ex[1].l; it.w[6] = ex[0].h; it.w[7] = ex[1].h;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int y = ey[0].lo + min(r, yext);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          int t = slot(y, ex[0].lo + min(c, xext));
+          asm volatile("" : "+v"(t));
+          it.a[r * 4 + c] = t;
+        }
+        // row / column factor r: the axis weights of the samples that touch it (.h weighs .lo, .l weighs .hi)
+        const int ry = ey[0].lo + r, rx = ex[0].lo + r;
+        it.w[r] = (r == 0 ? ey[0].h : 0.f) + (ey[0].hi == ry ? ey[0].l : 0.f) + (ey[1].lo == ry ? ey[1].h : 0.f) + (ey[1].hi == ry ? ey[1].l : 0.f);
+        it.w[4 + r] = (r == 0 ? ex[0].h : 0.f) + (ex[0].hi == rx ? ex[0].l : 0.f) + (ex[1].lo == rx ? ex[1].h : 0.f) + (ex[1].hi == rx ? ex[1].l : 0.f);
       }
+    }
     TT_MARK(2);
     if constexpr (DMA) {
       if (g.mode == kStageDma) {
@@ -655,6 +736,22 @@ static const TileConfig& tile_config() {   // development knobs, resolved ONCE (
   return cfg;
 }
 
+// Pooling arithmetic of the cluster kernel: 0 = merged taps where the bins are small (default), 1 = the reference's operation
+// order everywhere (bit-identical results).  Process-wide; read at launch (a captured hipGraph keeps what it was captured with).
+static std::atomic<int> g_exact{-1};
+int roi_align_exact() {
+  int v = g_exact.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("DTC_RA_EXACT");
+    v = (e && atoi(e) != 0) ? 1 : 0;
+    int expected = -1;
+    g_exact.compare_exchange_strong(expected, v);
+    v = g_exact.load(std::memory_order_relaxed);
+  }
+  return v;
+}
+void roi_align_set_exact(int on) { g_exact.store(on ? 1 : 0, std::memory_order_relaxed); }
+
 template <typename TIn, typename TOut, int NT, bool DMA>
 static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   const TileConfig& cfg = tile_config();
@@ -681,7 +778,7 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   while (!cfg.ch_block && cb > 32 && (long long)ngrp * ceil_div(p.channels, cb) < 2048) cb >>= 1;
   p.ch_block = cb;
   const int nct = ceil_div(p.channels, p.ch_block);
-  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT, DMA>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, (cfg.reverse ? 1 : 0) | (p.xcd_remap ? 0 : 2));
+  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT, DMA>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, (cfg.reverse ? 1 : 0) | (p.xcd_remap ? 0 : 2) | (roi_align_exact() ? 4 : 0));
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }
