@@ -805,12 +805,6 @@ DTC_API int dtc_roi_align_forward_packed(const dtc_feat_level* levels, int n_lev
                             pooled_w, sampling_ratio, out, out_dtype, stream);
 }
 
-DTC_API int dtc_roi_align_set_exact(int on) {
-  const int was = dtc::roi_align_exact();
-  if (on >= 0) dtc::roi_align_set_exact(on);
-  return was;
-}
-
 DTC_API size_t dtc_roi_align_workspace_bytes(int n_rois) { return dtc::roi_align_map_workspace_bytes(n_rois); }
 
 DTC_API int dtc_roi_align_forward_packed_ws(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,

@@ -114,8 +114,6 @@ __device__ __forceinline__ RoiHead load_roi_head(const RoiAlignParams& p, int ri
 }
 
 // launchers of the cluster-stationary kernel (roi_align_tile.hip); in_dtype / out_dtype are DTC_* codes
-int roi_align_exact();                 // 1: the cluster kernel pools in the reference's operation order (bit-identical)
-void roi_align_set_exact(int on);
 bool roi_align_tile_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
 int launch_roi_align_tile(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream);
 // launchers of the map-stationary kernel (roi_align_map.hip): single-level inputs whose whole map fits LDS

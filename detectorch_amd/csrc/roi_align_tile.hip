@@ -23,20 +23,16 @@
 // The LDS image is padded by one pixel slot every 8 pixels (phys = px + px/8): the transposing ds_write_b32 of 16
 // consecutive 4-pixel groups x 2 channels then spread over all 32 banks two-way (free for ds_write_b32) instead of eight-way.
 //
-// fp32 maps with unit column stride take the LDS-DMA staging path instead of the register pipeline of (2) (tile_passes_dma):
-// `buffer_load_dword ... lds` moves 16 window pixels x 4 channels per wave-instruction straight into the [pixel][4 channels]
-// image -- the transpose is done by the lane -> address mapping, no piece registers, no transposing ds_write, any 4-byte row
-// alignment (P5's 42 columns included) -- into one of TWO images, so the fetch of pass p+1 overlaps the pooling of pass p
-// with one barrier per pass.  16-bit maps keep the register pipeline (their pixels are widened to fp32 on the way in).
+// Serves the FPN box head (7x7 bins) and mask head (14x14 bins), fp32 / fp16 / bf16 maps.  What was built around it and measured
+// slower or equal -- a band sweep through an LDS ring, a per-launch preparation pass, LDS-DMA staging, merged-tap pooling --
+// is recorded in tools/r03/README.md with the commits that hold the code.
 //
 // Anything the cluster path does not cover takes a correct slow path inside the same kernel: levels whose rows are not
 // 16-byte aligned (P5: 42 columns) are staged with unaligned pieces or clamped scalar loads; a single RoI whose window exceeds
 // the LDS image is gathered per output straight from global memory; padding rows (level < 0) are zero-filled.
 #include <stdlib.h>
 
-#include <atomic>
 #include <mutex>
-#include <type_traits>
 
 #include "roi_align_common.h"
 
@@ -50,7 +46,7 @@ constexpr int kTileHdrBytes = kTileMaxK * (kTileRoiBytes + kTileGroupBytes) + 16
 // (512- and 1024-thread shapes -- K = 10 / 20 -- were built and measured in round 2: bit-exact, slower (0.42 / 0.54 ms against
 // 0.37), and spilling; removed in round 3, `git show 1687f14:detectorch_amd/csrc/roi_align_tile.hip`.)
 template <int NT> struct TileShape;
-template <> struct TileShape<256> { static constexpr int kUnits = 8, kWaves = 3, kLdsKB = 52, kDmaChunks = 16, kWavesDma = 4; };
+template <> struct TileShape<256> { static constexpr int kUnits = 8, kWaves = 3, kLdsKB = 52; };
 
 struct TileRoi {                        // 48 bytes
   int lvl, b, x0, x1, y0, y1, r, valid;   // window in feature pixels of its level, inclusive
@@ -114,22 +110,10 @@ struct TileTrace {};
 // LDS slot (16-byte units: one pixel x 4 channels) of window pixel px inside one quad image: one pad slot every 8 pixels
 __device__ __forceinline__ int tile_phys(int px) { return px + (px >> 3); }
 
-// Everything a lane needs to pool ITS (RoI, bin) from the LDS image, formed once per cluster.  Two forms, chosen per wavefront:
-//  * exact (mode 0): the reference's 2 x 2 samples x 4 taps, a[(iy * 2 + ix) * 4 + tap] = LDS byte offset (inside a quad image) of
-//    (y.lo,x.lo) (y.lo,x.hi) (y.hi,x.lo) (y.hi,x.hi), w = {yl0, yl1, yh0, yh1, xl0, xl1, xh0, xh1}: the same float32 operations
-//    in the same order as roi_align_cpu_loop.cpp:203-216 -- bit-identical results;
-//  * merged (mode 3 / 4): the 16 taps of a bin fall on the (y1.hi - y0.lo + 1) x (x1.hi - x0.lo + 1) pixels between its first and
-//    last sample -- 3 x 3 or fewer when the bin is at most 2 pixels wide, which is 3 of 4 RoIs of the FPN box head -- and bilinear
-//    weights are products of a row and a column factor, so  sum_samples sum_taps w v = sum_r Wy[r] sum_c Wx[c] v[r][c]  with
-//    Wy / Wx the per-row / per-column sums of the axis weights: 9 (mode 3) or 16 (mode 4) distinct LDS reads and 24 / 40 packed
-//    FMAs per channel quad instead of 16 reads, 16 weight products and 64 packed multiplies / adds.  a[r * 4 + c] = offset of
-//    pixel (row min(r, rows - 1), column min(c, columns - 1)) of that neighbourhood (the clamped copies carry weight 0),
-//    w = {Wy0..3, Wx0..3}.  Same real-number result, different rounding: within a few float32 ulps of the reference (the
-//    contract is 1e-4), NOT bit-identical -- dtc_roi_align_set_exact(1) / DTC_RA_EXACT=1 selects mode 0 everywhere.
+// Everything a lane needs to pool ITS (RoI, bin) from the LDS image, formed once per cluster.
 struct TileItem {
-  int a[16];
-  float w[8];
-  int mode;                 // wave-uniform: 0, 3, 4
+  int a[2][2][4];           // [iy][ix][tap]: LDS byte offsets (inside a quad image) of (y.lo,x.lo) (y.lo,x.hi) (y.hi,x.lo) (y.hi,x.hi)
+  float yl[2], yh[2], xl[2], xh[2];
   bool on;
 };
 
@@ -147,7 +131,7 @@ template <> __device__ __forceinline__ void store_quad<bf16_t>(bf16_t* d, float4
   *reinterpret_cast<uint2*>(d) = r;
 }
 
-enum { kStageScalar = 0, kStageVec = 1, kStageVecUnaligned = 2, kStageDma = 3 };
+enum { kStageScalar = 0, kStageVec = 1, kStageVecUnaligned = 2 };
 
 struct TileGeom {            // one cluster, all uniform
   int first, count;          // RoIs troi[first .. first + count)
@@ -157,115 +141,13 @@ struct TileGeom {            // one cluster, all uniform
   int mode;                  // kStage*
 };
 
-// slab of the pass that was pooled last: [RoI of the cluster][4 * nq channels][bins] float32, contiguous per RoI exactly like
-// the [R, C, PH, PW] output -> 16-byte stores (the output offset of channel cs is a multiple of 4 elements when C % 4 == 0)
-template <typename TOut, int NT>
-__device__ __forceinline__ void tile_store_slab(const RoiAlignParams& p, const TileRoi* troi, const TileGeom& g, const float* slab,
-                                                int c0, int nc, int bins, int cs, int nq) {
-  const int tid = threadIdx.x;
-  const bool quad_ok = ((p.channels | c0) & 3) == 0;
-  const int nch = min(4 * nq, nc - cs);
-  TOut* out = reinterpret_cast<TOut*>(p.out);
-  if (quad_ok && nch == 4 * nq) {
-    const int n4 = nq * bins, total = g.count * n4;
-    const float r4 = 1.0f / (float)n4;
-    for (int idx = tid; idx < total; idx += NT) {
-      const int k = (int)(((float)idx + 0.5f) * r4);            // exact for idx < 2^13
-      const int e = idx - k * n4;
-      const float4 val = reinterpret_cast<const float4*>(slab)[idx];
-      store_quad<TOut>(out + ((size_t)troi[g.first + k].r * p.channels + c0 + cs) * bins + 4 * e, val);
-    }
-  } else {
-    const int per = nch * bins, total = g.count * per;
-    for (int idx = tid; idx < total; idx += NT) {
-      const int k = idx / per, e = idx - k * per;
-      out[((size_t)troi[g.first + k].r * p.channels + c0 + cs) * bins + e] = from_f32<TOut>(slab[k * 4 * nq * bins + e]);
-    }
-  }
-}
-
-__device__ __forceinline__ f32x2 pk_fma(float a, f32x2 b, f32x2 c) {
-  const f32x2 av = {a, a};
-  return __builtin_elementwise_fma(av, b, c);          // v_pk_fma_f32
-}
-
-// merged-tap pooling of one quad image: ROWS x COLS pixels, row factors Wy = w[0..3], column factors Wx = w[4..7]
-template <int ROWS, int COLS>
-__device__ __forceinline__ void tile_pool_merged_quad(const char* wq, const TileItem& it, float* o, int bins) {
-  f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-  constexpr int RB = ROWS * COLS <= 9 ? ROWS : 2;       // rows whose taps are in flight together (<= 9 x 4 registers)
-#pragma unroll
-  for (int r0 = 0; r0 < ROWS; r0 += RB) {
-    f32x4 t[RB][COLS];
-#pragma unroll
-    for (int r = 0; r < RB; r++)
-#pragma unroll
-      for (int c = 0; c < COLS; c++)
-        t[r][c] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(wq + it.a[(r0 + r) * 4 + c], 16));
-#pragma unroll
-    for (int r = 0; r < RB; r++) {
-      f32x2 s01 = it.w[4] * t[r][0].lo, s23 = it.w[4] * t[r][0].hi;
-#pragma unroll
-      for (int c = 1; c < COLS; c++) { s01 = pk_fma(it.w[4 + c], t[r][c].lo, s01); s23 = pk_fma(it.w[4 + c], t[r][c].hi, s23); }
-      a01 = pk_fma(it.w[r0 + r], s01, a01);
-      a23 = pk_fma(it.w[r0 + r], s23, a23);
-    }
-    if (RB < ROWS) __builtin_amdgcn_sched_barrier(0);
-  }
-  const float a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
-  o[0] = a0 * 0.25f; o[bins] = a1 * 0.25f; o[2 * bins] = a2 * 0.25f; o[3 * bins] = a3 * 0.25f;
-}
-
-// The lane's (RoI, bin) pooled from nq quad images (img: the first one, plane_bytes apart) into its slab column `so`.
-__device__ __forceinline__ void tile_pool(const char* img, int plane_bytes, const TileItem& it, float* so, int bins, int nq) {
-  if (it.mode == 3) {
-#pragma unroll 1
-    for (int q = 0; q < nq; q++) tile_pool_merged_quad<3, 3>(img + uni(q * plane_bytes), it, so + uni(4 * q * bins), bins);
-    return;
-  }
-  if (it.mode == 4) {
-#pragma unroll 1
-    for (int q = 0; q < nq; q++) tile_pool_merged_quad<4, 4>(img + uni(q * plane_bytes), it, so + uni(4 * q * bins), bins);
-    return;
-  }
-#pragma unroll 1
-  for (int q = 0; q < nq; q++) {
-    // uniform quad offset, opaque to the optimiser: otherwise every tap address becomes its own induction variable
-    const char* wq = img + uni(q * plane_bytes);
-    // two channels per instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE results, twice the fp32 rate of the scalar forms)
-    f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-    // reference order: for iy { for ix { acc += w1*v1 + w2*v2 + w3*v3 + w4*v4 } }   (roi_align_cpu_loop.cpp:203-214)
-#pragma unroll
-    for (int iy = 0; iy < 2; iy++) {
-      f32x4 t[2][4];
-#pragma unroll
-      for (int ix = 0; ix < 2; ix++)
-#pragma unroll
-        for (int k = 0; k < 4; k++)                                       // 8 ds_read_b128 in flight per sample row
-          t[ix][k] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(wq + it.a[(iy * 2 + ix) * 4 + k], 16));
-#pragma unroll
-      for (int ix = 0; ix < 2; ix++) {
-        const float yl = it.w[iy], yh = it.w[2 + iy], xl = it.w[4 + ix], xh = it.w[6 + ix];
-        const float w1 = yh * xh, w2 = yh * xl, w3 = yl * xh, w4 = yl * xl;                      // roi_align_cpu_loop.cpp:95
-        a01 += w1 * t[ix][0].lo + w2 * t[ix][1].lo + w3 * t[ix][2].lo + w4 * t[ix][3].lo;    // :208-211
-        a23 += w1 * t[ix][0].hi + w2 * t[ix][1].hi + w3 * t[ix][2].hi + w4 * t[ix][3].hi;
-      }
-      __builtin_amdgcn_sched_barrier(0);      // keep the two sample rows apart: 32, not 64, tap registers live
-    }
-    // :216  output_val /= count ; count == 4 -> x * 0.25f is the same float32
-    float* o = so + uni(4 * q * bins);
-    const float a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
-    o[0] = a0 * 0.25f; o[bins] = a1 * 0.25f; o[2 * bins] = a2 * 0.25f; o[3 * bins] = a3 * 0.25f;
-  }
-}
-
 // One cluster: stage + pool every channel quad of this workgroup's channel block.
 // Register pipeline: a thread carries up to kUnits 16-byte row pieces per pass; unit u = q * KC + i is piece-chunk i
 // (16 consecutive pieces x 4 channels per wave-instruction) of channel quad q, so a pass stages nq_pass quads with
 // KC * nq_pass <= kUnits.  Per pass:   commit(p) + store_slab(p-1) | barrier | issue(p+1) + pool(p) -> slab | barrier
 // i.e. the loads of pass p+1 are in flight (registers) while pass p is pooled, and the pooled [RoI][channel][bin] slab of
 // pass p leaves for global memory as contiguous 16-byte stores while pass p+1 is being committed.
-template <typename TIn, typename TOut, int NT, bool VEC>
+template <typename TIn, typename TOut, int NT>
 __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_feat_level& L, const TIn* fbase, int c0, int nc,
                                             int bins, float* slab, float* win, const TileRoi* troi, const TileGeom& g,
                                             const TileItem& it, int rl, int bin, TileTrace& tt) {
@@ -277,7 +159,7 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
   const int KC = ceil_div(nchunk, NW);
   const float rinv = 1.0f / (float)ngx;
   const int nq_tot = ceil_div(nc, 4);
-  const bool vec = VEC && g.mode != kStageScalar;      // VEC == false (the DMA kernel): only the scalar fallback is compiled
+  const bool vec = g.mode != kStageScalar;
   uint32_t uoff[U];     // byte offset of the unit's piece (row, 4 pixels, channel 4q + cl) from the pass base plane; bits 30-31:
                         // how many pixels the piece was shifted left to stay inside its row (kStageVecUnaligned)
   int ulds[U];          // float index of (first pixel of the piece, channel cl) in the LDS image
@@ -353,7 +235,29 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
       }
     }
   };
-  auto store_slab = [&](int cs, int nq) { tile_store_slab<TOut, NT>(p, troi, g, slab, c0, nc, bins, cs, nq); };
+  // slab of the pass that was pooled last: [RoI of the cluster][4 * nq channels][bins] float32, contiguous per RoI exactly like
+  // the [R, C, PH, PW] output -> 16-byte stores (the output offset of channel cs is a multiple of 4 elements when C % 4 == 0)
+  const bool quad_ok = ((p.channels | c0) & 3) == 0;
+  auto store_slab = [&](int cs, int nq) {
+    const int nch = min(4 * nq, nc - cs);
+    TOut* out = reinterpret_cast<TOut*>(p.out);
+    if (quad_ok && nch == 4 * nq) {
+      const int n4 = nq * bins, total = g.count * n4;
+      const float r4 = 1.0f / (float)n4;
+      for (int idx = tid; idx < total; idx += NT) {
+        const int k = (int)(((float)idx + 0.5f) * r4);            // exact for idx < 2^13
+        const int e = idx - k * n4;
+        const float4 val = reinterpret_cast<const float4*>(slab)[idx];
+        store_quad<TOut>(out + ((size_t)troi[g.first + k].r * p.channels + c0 + cs) * bins + 4 * e, val);
+      }
+    } else {
+      const int per = nch * bins, total = g.count * per;
+      for (int idx = tid; idx < total; idx += NT) {
+        const int k = idx / per, e = idx - k * per;
+        out[((size_t)troi[g.first + k].r * p.channels + c0 + cs) * bins + e] = from_f32<TOut>(slab[k * 4 * nq * bins + e]);
+      }
+    }
+  };
 
   TT_MARK(3);
   if (vec) issue(0);
@@ -370,7 +274,38 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
     TT_MARK(6);
     if (vec && qs + nq_pass < nq_tot) issue(cs + 4 * nq_pass);    // next pass: in flight (registers) while this one is pooled
     TT_MARK(7);
-    if (it.on) tile_pool(reinterpret_cast<const char*>(win), plane * 16, it, slab + rl * (4 * nq_cur * bins) + bin, bins, nq_cur);
+    if (it.on) {
+      float* so = slab + rl * (4 * nq_cur * bins) + bin;
+#pragma unroll 1
+      for (int q = 0; q < nq_cur; q++) {
+        // uniform quad offset, opaque to the optimiser: otherwise every tap address becomes its own induction variable
+        const char* wq = reinterpret_cast<const char*>(win) + uni(q * plane * 16);
+        // two channels per instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE results, twice the fp32 rate of the scalar forms)
+        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+        // reference order: for iy { for ix { acc += w1*v1 + w2*v2 + w3*v3 + w4*v4 } }   (roi_align_cpu_loop.cpp:203-214)
+#pragma unroll
+        for (int iy = 0; iy < 2; iy++) {
+          f32x4 t[2][4];
+#pragma unroll
+          for (int ix = 0; ix < 2; ix++)
+#pragma unroll
+            for (int k = 0; k < 4; k++)                                       // 8 ds_read_b128 in flight per sample row
+              t[ix][k] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(wq + it.a[iy][ix][k], 16));
+#pragma unroll
+          for (int ix = 0; ix < 2; ix++) {
+            const float w1 = it.yh[iy] * it.xh[ix], w2 = it.yh[iy] * it.xl[ix];               // roi_align_cpu_loop.cpp:95
+            const float w3 = it.yl[iy] * it.xh[ix], w4 = it.yl[iy] * it.xl[ix];
+            a01 += w1 * t[ix][0].lo + w2 * t[ix][1].lo + w3 * t[ix][2].lo + w4 * t[ix][3].lo;    // :208-211
+            a23 += w1 * t[ix][0].hi + w2 * t[ix][1].hi + w3 * t[ix][2].hi + w4 * t[ix][3].hi;
+          }
+          __builtin_amdgcn_sched_barrier(0);      // keep the two sample rows apart: 32, not 64, tap registers live
+        }
+        // :216  output_val /= count ; count == 4 -> x * 0.25f is the same float32
+        float* o = so + uni(4 * q * bins);
+        const float a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
+        o[0] = a0 * 0.25f; o[bins] = a1 * 0.25f; o[2 * bins] = a2 * 0.25f; o[3 * bins] = a3 * 0.25f;
+      }
+    }
     TT_MARK(8);
     __syncthreads();
     TT_MARK(9);
@@ -378,72 +313,6 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
   }
   if (nq_prev) store_slab(cs_prev, nq_prev);   // the next cluster writes the slab only behind its own first barrier
   TT_MARK(10);
-}
-
-// LDS-DMA staging (fp32 maps, unit column stride).  The window image is LINEAR here -- slot(row, col) = row * tw + col, no pad
-// slots -- cut into chunks of 16 pixels; one `buffer_load_dword ... lds` per chunk: lane l fetches pixel (l >> 2) of the
-// chunk from channel plane (l & 3) and the hardware writes the 64 dwords lane-linearly = [16 pixels][4 channels], the layout
-// the tap gather reads.  The instruction is issued from inline assembly: the compiler would otherwise order every later LDS access
-// of the wave behind it with s_waitcnt vmcnt(0) (it cannot tell the two images apart) and the fetch would not overlap the
-// pooling.  Per pass:   vmcnt(0) | barrier | issue(p+1 -> other image) | store_slab(p-1) | pool(p) -> slab[p & 1]
-// vmcnt(0) covers the wave's own chunks of pass p (issued a whole pooling phase ago); the barrier publishes every wave's.
-// M0 carries the LDS byte address of lane 0's dword; clang flags it as a reserved register in a clobber list, which is the point.
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ void tile_dma_dword(u32x4 srd, uint32_t lds_byte, uint32_t voff, uint32_t soff) {
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds_byte), "v"(voff), "s"(srd), "s"(soff) : "memory", "m0");
-}
-#pragma clang diagnostic pop
-
-template <typename TOut, int NT>
-__device__ __forceinline__ void tile_passes_dma(const RoiAlignParams& p, const dtc_feat_level& L, const float* fbase, int c0, int nc,
-                                                int bins, float* slab, int slab_half, unsigned char* win, int buf_bytes,
-                                                const TileRoi* troi, const TileGeom& g, const TileItem& it, int rl, int bin) {
-  constexpr int NW = NT / 64;
-  constexpr int J = TileShape<NT>::kDmaChunks;
-  const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
-  const int tw = 4 * g.ngx, npx = 4 * g.npos, nchunk = (npx + 15) >> 4;
-  const int nj = nchunk > wv ? (nchunk - wv + NW - 1) / NW : 0;       // chunks wv, wv + NW, ... of this wave
-  const int plane_bytes = nchunk * 256, nq_pass = g.nq_pass, nq_tot = ceil_div(nc, 4);
-  const float rinv = 1.0f / (float)tw;
-  const int sh32 = (int)L.stride_h, sc32 = (int)L.stride_c;
-  uint32_t voff[J];            // byte offset of (this lane's pixel of chunk j, channel lane & 3) inside the pass base plane
-#pragma unroll
-  for (int j = 0; j < J; j++) {
-    const int px = min((wv + NW * j) * 16 + (lane >> 2), npx - 1);    // slots past the window: a copy of its last pixel
-    const int row = (int)(((float)px + 0.5f) * rinv);                 // exact: px < 2^13, distance to an integer >= 0.5 / tw
-    const int col = min(g.x0a + px - row * tw, L.width - 1);          // the last 4-pixel group of a row may overhang the map
-    voff[j] = (uint32_t)((g.y0 + row) * sh32 + col + (lane & 3) * sc32) * 4u;
-  }
-  const uint64_t ga = (uint64_t)reinterpret_cast<uintptr_t>(fbase);
-  const u32x4 srd = {(uint32_t)uni((int)(uint32_t)ga), (uint32_t)uni((int)((uint32_t)(ga >> 32) & 0xffffu)), 0xffffffffu, 0x00020000u};
-  const uint32_t pass_bytes = (uint32_t)(L.stride_c * 4);
-  const uint32_t win_lds = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void*)win);
-  auto issue = [&](int cs, int b) {
-#pragma unroll 1
-    for (int q = 0; q < nq_pass; q++) {
-      const uint32_t soff = (uint32_t)(cs + 4 * q) * pass_bytes;
-      const uint32_t l0 = win_lds + (uint32_t)(b * buf_bytes + q * plane_bytes + wv * 256);
-#pragma unroll
-      for (int j = 0; j < J; j++)
-        if (j < nj) tile_dma_dword(srd, l0 + (uint32_t)(j * NW * 256), voff[j], soff);
-    }
-  };
-  issue(0, 0);
-  int cs_prev = 0, nq_prev = 0, b = 0;
-#pragma unroll 1
-  for (int qs = 0; qs < nq_tot; qs += nq_pass, b ^= 1) {
-    const int cs = 4 * qs;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (qs + nq_pass < nq_tot) issue(cs + 4 * nq_pass, b ^ 1);      // lands while this pass is pooled
-    if (nq_prev) tile_store_slab<TOut, NT>(p, troi, g, slab + (b ^ 1) * slab_half, c0, nc, bins, cs_prev, nq_prev);
-    if (it.on)
-      tile_pool(reinterpret_cast<const char*>(win) + b * buf_bytes, plane_bytes, it, slab + b * slab_half + rl * (4 * nq_pass * bins) + bin, bins, nq_pass);
-    cs_prev = cs; nq_prev = nq_pass;
-  }
-  __syncthreads();
-  if (nq_prev) tile_store_slab<TOut, NT>(p, troi, g, slab + (b ^ 1) * slab_half, c0, nc, bins, cs_prev, nq_prev);
 }
 
 // Work item of block b: XCD x (= b % 8) owns a contiguous slice of the (cluster group, channel block) items, as in
@@ -458,8 +327,8 @@ __device__ __forceinline__ int tile_work_item(int b, int n, int reverse) {
   return start + ((reverse & 1) ? qx - 1 - j : j);
 }
 
-template <typename TIn, typename TOut, int NT, bool DMA>
-__global__ __launch_bounds__(NT, DMA ? TileShape<NT>::kWavesDma : TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct, int reverse) {
+template <typename TIn, typename TOut, int NT>
+__global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct, int reverse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileRoi* troi = reinterpret_cast<TileRoi*>(smem);
   TileGroup* tgrp = reinterpret_cast<TileGroup*>(smem + kTileMaxK * kTileRoiBytes);
@@ -471,25 +340,6 @@ __global__ __launch_bounds__(NT, DMA ? TileShape<NT>::kWavesDma : TileShape<NT>:
   const int win_bytes = lds_bytes - kTileHdrBytes - slab_bytes;
   constexpr int NW = NT / 64;
   constexpr int kMaxPos = TileShape<NT>::kUnits * NW * 16;                  // 16-byte pieces the register pipeline can carry per quad
-  // LDS-DMA staging: the image region holds TWO images, the slab region two slabs of nq_cap / 2 quads
-  static_assert(!DMA || std::is_same<TIn, float>::value, "LDS-DMA staging moves dwords: fp32 maps only");
-  const int buf_bytes = (win_bytes / 2) & ~255;
-  const int dma_max_px = min(buf_bytes / 16, TileShape<NT>::kDmaChunks * NW * 16);
-  // staging mode of a level: unit column stride + whole channel quads + 30-bit lane offsets -> LDS-DMA (fp32) or 16-byte pieces
-  // (16-byte aligned rows), unaligned pieces with the last one of a row shifted left (4-byte aligned rows: width % 4 != 0);
-  // anything else (strided columns, channel tails) -> clamped scalar loads
-  auto stage_mode = [&](const dtc_feat_level& L, int c0_, int nc_) {
-    const int esz = (int)sizeof(TIn);
-    const bool lin = L.stride_w == 1 && ((nc_ | c0_) & 3) == 0 && L.stride_h > 0 && L.stride_c > 0 &&
-                     L.stride_h * L.height + L.stride_c * 4 * TileShape<NT>::kUnits < (1ll << 26);     // lane offsets fit 30 bits
-    if (!lin) return (int)kStageScalar;
-    if (DMA) return (int)(nq_cap >= 2 && (reinterpret_cast<uintptr_t>(L.data) & 3) == 0 ? kStageDma : kStageScalar);
-    const bool al16 = ((L.width | L.stride_h | L.stride_c | L.stride_n) & 3) == 0 &&
-                      (reinterpret_cast<uintptr_t>(L.data) & (4 * sizeof(TIn) - 1)) == 0;
-    const bool al4 = L.width >= 4 && (((L.width | L.stride_h | L.stride_c | L.stride_n) * esz) & 3) == 0 &&
-                     (reinterpret_cast<uintptr_t>(L.data) & 3) == 0;
-    return (int)(al16 ? kStageVec : al4 ? kStageVecUnaligned : kStageScalar);
-  };
   const int tid = threadIdx.x;
   const int nct = ceil_div(p.channels, p.ch_block);
   const int wi = tile_work_item(blockIdx.x, gridDim.x, reverse);
@@ -536,11 +386,7 @@ __global__ __launch_bounds__(NT, DMA ? TileShape<NT>::kWavesDma : TileShape<NT>:
       else if (a_lvl < 0) g.kind = kGrpZero;
       else {
         const int ngx0 = (a_x1 >> 2) - (a_x0 >> 2) + 1, th0 = a_y1 - a_y0 + 1, npos0 = th0 * ngx0;
-        const bool a_dma = stage_mode(p.lv[a_lvl], c0, nc) == kStageDma;
-        auto fits = [&](int npos) {      // a window of npos 4-pixel groups can be staged
-          return a_dma ? 4 * npos <= dma_max_px : (npos <= kMaxPos && (4 * npos + (npos >> 1) + 1) * 16 <= win_bytes);
-        };
-        if (!fits(npos0) || bins > NT) {
+        if (npos0 > kMaxPos || (4 * npos0 + (npos0 >> 1) + 1) * 16 > win_bytes || bins > NT) {
           g.kind = kGrpGather;
         } else {
           g.kind = kGrpPool;
@@ -555,7 +401,7 @@ __global__ __launch_bounds__(NT, DMA ? TileShape<NT>::kWavesDma : TileShape<NT>:
             const int n_x0 = bc(t.x0, js), n_x1 = bc(t.x1, js), n_y0 = bc(t.y0, js), n_y1 = bc(t.y1, js);
             const int ux0 = min(g.x0, n_x0), ux1 = max(g.x1, n_x1), uy0 = min(g.y0, n_y0), uy1 = max(g.y1, n_y1);
             const int ungx = (ux1 >> 2) - (ux0 >> 2) + 1, uth = uy1 - uy0 + 1, unpos = uth * ungx;
-            if (!fits(unpos)) break;
+            if (unpos > kMaxPos || (4 * unpos + (unpos >> 1) + 1) * 16 > win_bytes) break;
             const long long n_px = (long long)(n_y1 - n_y0 + 1) * (n_x1 - n_x0 + 1);
             const long long u_px = (long long)uth * (ux1 - ux0 + 1);
             if (u_px * 100 > (sum_px + n_px) * merge_pct) break;
@@ -620,15 +466,19 @@ __global__ __launch_bounds__(NT, DMA ? TileShape<NT>::kWavesDma : TileShape<NT>:
     const int tw = 4 * g.ngx, th = gy1 - gy0 + 1;
     g.npos = th * g.ngx;
     g.plane = 4 * g.npos + (g.npos >> 1) + 1;           // slots per quad image
-    g.mode = stage_mode(L, c0, nc);
-    const int nq_blk = ceil_div(nc, 4);
-    if (g.mode == kStageDma) {
-      g.nq_pass = max(1, min(min(buf_bytes / (((4 * g.npos + 15) >> 4) * 256), nq_cap >> 1), nq_blk));
-    } else {
-      const int KC = ceil_div((g.npos + 15) >> 4, NW);
-      g.nq_pass = max(1, min(min(win_bytes / (g.plane * 16), TileShape<NT>::kUnits / KC), min(nq_blk, nq_cap)));
-    }
-    while (nq_blk % g.nq_pass) g.nq_pass--;        // every pass full: no partial-pass code in the staging pipeline
+    // staging mode: 16-byte aligned rows -> plain 16-byte pieces; 4-byte aligned rows (width % 4 != 0) -> unaligned pieces,
+    // the last one of a row shifted left; anything else (strided columns, channel tails) -> scalar loads
+    const int esz = (int)sizeof(TIn);
+    const bool lin = L.stride_w == 1 && ((nc | c0) & 3) == 0 && L.stride_h > 0 && L.stride_c > 0 &&
+                     L.stride_h * L.height + L.stride_c * 4 * TileShape<NT>::kUnits < (1ll << 26);     // lane offsets fit 30 bits
+    const bool al16 = ((L.width | L.stride_h | L.stride_c | L.stride_n) & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(L.data) & (4 * sizeof(TIn) - 1)) == 0;
+    const bool al4 = L.width >= 4 && (((L.width | L.stride_h | L.stride_c | L.stride_n) * esz) & 3) == 0 &&
+                     (reinterpret_cast<uintptr_t>(L.data) & 3) == 0;
+    g.mode = !lin ? kStageScalar : al16 ? kStageVec : al4 ? kStageVecUnaligned : kStageScalar;
+    const int KC = ceil_div((g.npos + 15) >> 4, NW);
+    g.nq_pass = max(1, min(min(win_bytes / (g.plane * 16), TileShape<NT>::kUnits / KC), min(ceil_div(nc, 4), nq_cap)));
+    while (ceil_div(nc, 4) % g.nq_pass) g.nq_pass--;        // every pass full: no partial-pass code in the staging pipeline
     // ---- the lane's item -------------------------------------------------------------------------------------------
     const int n_it = count * bins;
     TileItem it;
@@ -637,59 +487,26 @@ __global__ __launch_bounds__(NT, DMA ? TileShape<NT>::kWavesDma : TileShape<NT>:
     const int rl = itx / bins, bin = itx - rl * bins;
     const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
     const TileRoi hd = troi[first + rl];     // sh / sw / bin sizes as phase A formed them
-    AxisEntry ey[2], ex[2];
+    int ylo[2], yhi[2], xlo[2], xhi[2];      // window-relative: rows premultiplied by the window width
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      ey[i] = make_axis(hd.sh, hd.bin_h, ph, i, 2, L.height);
-      ex[i] = make_axis(hd.sw, hd.bin_w, pw, i, 2, L.width);
+      const AxisEntry ey = make_axis(hd.sh, hd.bin_h, ph, i, 2, L.height);
+      const AxisEntry ex = make_axis(hd.sw, hd.bin_w, pw, i, 2, L.width);
+      it.yl[i] = ey.l; it.yh[i] = ey.h; it.xl[i] = ex.l; it.xh[i] = ex.h;
+      ylo[i] = (ey.lo - gy0) * tw; yhi[i] = (ey.hi - gy0) * tw;
+      xlo[i] = ex.lo - g.x0a; xhi[i] = ex.hi - g.x0a;
     }
-    // window-relative slot of pixel (row y, column x) of the level
-    auto slot = [&](int y, int x) {
-      const int px = (y - gy0) * tw + (x - g.x0a);
-      return (g.mode == kStageDma ? px : tile_phys(px)) << 4;            // DMA image: linear
-    };
-    // pooling form of this wavefront: merged taps when the neighbourhood of every lane is at most 3 x 3 / 4 x 4 pixels
-    const int yext = ey[1].hi - ey[0].lo, xext = ex[1].hi - ex[0].lo;     // rows - 1, columns - 1 (positions are non-decreasing)
-    const unsigned long long all = __builtin_amdgcn_ballot_w64(true);
-    const bool fit3 = __builtin_amdgcn_ballot_w64(yext <= 2 && xext <= 2) == all;
-    const bool fit4 = __builtin_amdgcn_ballot_w64(yext <= 3 && xext <= 3) == all;
-    it.mode = (reverse & 4) ? 0 : fit3 ? 3 : fit4 ? 4 : 0;
-    if (it.mode == 0) {
 #pragma unroll
-      for (int iy = 0; iy < 2; iy++)
+    for (int iy = 0; iy < 2; iy++)
 #pragma unroll
-        for (int ix = 0; ix < 2; ix++) {
-          int t0 = slot(ey[iy].lo, ex[ix].lo), t1 = slot(ey[iy].lo, ex[ix].hi), t2 = slot(ey[iy].hi, ex[ix].lo), t3 = slot(ey[iy].hi, ex[ix].hi);
-          asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));   // one finished VGPR per tap: do not re-derive in the loop
-          const int k = (iy * 2 + ix) * 4;
-          it.a[k] = t0; it.a[k + 1] = t1; it.a[k + 2] = t2; it.a[k + 3] = t3;
-        }
-      it.w[0] = ey[0].l; it.w[1] = ey[1].l; it.w[2] = ey[0].h; it.w[3] = ey[1].h;
-      it.w[4] = ex[0].l; it.w[5] = ex[1].l; it.w[6] = ex[0].h; it.w[7] = ex[1].h;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int y = ey[0].lo + min(r, yext);
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          int t = slot(y, ex[0].lo + min(c, xext));
-          asm volatile("" : "+v"(t));
-          it.a[r * 4 + c] = t;
-        }
-        // row / column factor r: the axis weights of the samples that touch it (.h weighs .lo, .l weighs .hi)
-        const int ry = ey[0].lo + r, rx = ex[0].lo + r;
-        it.w[r] = (r == 0 ? ey[0].h : 0.f) + (ey[0].hi == ry ? ey[0].l : 0.f) + (ey[1].lo == ry ? ey[1].h : 0.f) + (ey[1].hi == ry ? ey[1].l : 0.f);
-        it.w[4 + r] = (r == 0 ? ex[0].h : 0.f) + (ex[0].hi == rx ? ex[0].l : 0.f) + (ex[1].lo == rx ? ex[1].h : 0.f) + (ex[1].hi == rx ? ex[1].l : 0.f);
+      for (int ix = 0; ix < 2; ix++) {
+        int t0 = tile_phys(ylo[iy] + xlo[ix]) << 4, t1 = tile_phys(ylo[iy] + xhi[ix]) << 4;
+        int t2 = tile_phys(yhi[iy] + xlo[ix]) << 4, t3 = tile_phys(yhi[iy] + xhi[ix]) << 4;
+        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));   // one finished VGPR per tap: do not re-derive in the loop
+        it.a[iy][ix][0] = t0; it.a[iy][ix][1] = t1; it.a[iy][ix][2] = t2; it.a[iy][ix][3] = t3;
       }
-    }
     TT_MARK(2);
-    if constexpr (DMA) {
-      if (g.mode == kStageDma) {
-        tile_passes_dma<TOut, NT>(p, L, fbase, c0, nc, bins, slab, (slab_bytes >> 3), reinterpret_cast<unsigned char*>(win), buf_bytes, troi, g, it, rl, bin);
-        continue;
-      }
-    }
-    tile_passes<TIn, TOut, NT, !DMA>(p, L, fbase, c0, nc, bins, slab, win, troi, g, it, rl, bin, tt);
+    tile_passes<TIn, TOut, NT>(p, L, fbase, c0, nc, bins, slab, win, troi, g, it, rl, bin, tt);
   }
 #ifdef DTC_TILE_TRACE
   if (tid == 0 && blockIdx.x < 16384) {
@@ -717,8 +534,7 @@ struct TileConfig {
   int k = 0;           // RoIs per workgroup (0: threads / bins)
   int ch_block = 0;    // channels per workgroup (0: chosen per launch)
   int merge_pct = 250; // a cluster may stage at most this % of the pixels its members would stage separately
-  int nq_cap = 0;      // channel quads per pass, upper bound (0: 4, fp32 maps 2) -- sizes the LDS output slab
-  int dma = 0;         // fp32 maps: 1 = LDS-DMA staging into two images (measured 0.40 ms against 0.37 for the register pipeline)
+  int nq_cap = 0;      // channel quads per pass, upper bound (0: 4) -- sizes the LDS output slab
   int reverse = 1;     // walk an XCD's slice of the visiting order back to front (heaviest workgroups first)
 };
 static const TileConfig& tile_config() {   // development knobs, resolved ONCE (thread-safe static initialisation)
@@ -729,30 +545,13 @@ static const TileConfig& tile_config() {   // development knobs, resolved ONCE (
     if (const char* e = getenv("DTC_RA_TILE_MERGE")) { const int v = atoi(e); if (v >= 100 && v <= 100000) c.merge_pct = v; }
     if (const char* e = getenv("DTC_RA_TILE_NQCAP")) { const int v = atoi(e); if (v >= 1 && v <= 8) c.nq_cap = v; }
     if (const char* e = getenv("DTC_RA_TILE_REVERSE")) c.reverse = atoi(e) != 0;
-    if (const char* e = getenv("DTC_RA_TILE_DMA")) c.dma = atoi(e) != 0;
     if (const char* e = getenv("DTC_RA_TILE_CHBLOCK")) { const int v = atoi(e); if (v >= 4 && (v & 3) == 0) c.ch_block = v; }
     return c;
   }();
   return cfg;
 }
 
-// Pooling arithmetic of the cluster kernel: 0 = merged taps where the bins are small (default), 1 = the reference's operation
-// order everywhere (bit-identical results).  Process-wide; read at launch (a captured hipGraph keeps what it was captured with).
-static std::atomic<int> g_exact{-1};
-int roi_align_exact() {
-  int v = g_exact.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("DTC_RA_EXACT");
-    v = (e && atoi(e) != 0) ? 1 : 0;
-    int expected = -1;
-    g_exact.compare_exchange_strong(expected, v);
-    v = g_exact.load(std::memory_order_relaxed);
-  }
-  return v;
-}
-void roi_align_set_exact(int on) { g_exact.store(on ? 1 : 0, std::memory_order_relaxed); }
-
-template <typename TIn, typename TOut, int NT, bool DMA>
+template <typename TIn, typename TOut, int NT>
 static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   const TileConfig& cfg = tile_config();
   const int bins = p.pooled_h * p.pooled_w;
@@ -764,11 +563,11 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_tile<TIn, TOut, NT, DMA>),
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_tile<TIn, TOut, NT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   if (attr_rc != hipSuccess) return DTC_ELAUNCH;
-  const int nq_cap = cfg.nq_cap ? cfg.nq_cap : (DMA ? 2 : 4);     // DMA staging: two slabs of nq_cap / 2 quads
+  const int nq_cap = cfg.nq_cap ? cfg.nq_cap : 4;
   if (kTileHdrBytes + K * bins * 16 * nq_cap + 20 * 1024 > lds_b) return DTC_EUNSUPPORTED;
   const int ngrp = ceil_div(p.n_rois, K);
   // channels per workgroup: the per-cluster setup (geometry, item registers) is paid once per block; keep >= ~4 workgroups per CU
@@ -778,17 +577,14 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   while (!cfg.ch_block && cb > 32 && (long long)ngrp * ceil_div(p.channels, cb) < 2048) cb >>= 1;
   p.ch_block = cb;
   const int nct = ceil_div(p.channels, p.ch_block);
-  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT, DMA>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, (cfg.reverse ? 1 : 0) | (p.xcd_remap ? 0 : 2) | (roi_align_exact() ? 4 : 0));
+  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, (cfg.reverse ? 1 : 0) | (p.xcd_remap ? 0 : 2));
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }
 
 template <typename TIn, typename TOut>
 static int launch_tile_t(const RoiAlignParams& p, hipStream_t stream) {
-  if constexpr (std::is_same<TIn, float>::value) {
-    if (tile_config().dma) return launch_tile_nt<TIn, TOut, 256, true>(p, stream);
-  }
-  return launch_tile_nt<TIn, TOut, 256, false>(p, stream);
+  return launch_tile_nt<TIn, TOut, 256>(p, stream);
 }
 
 bool roi_align_tile_supported(const RoiAlignParams& p, int in_dtype, int out_dtype) {

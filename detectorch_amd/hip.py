@@ -80,8 +80,6 @@ def lib():
     L.dtc_fpn_collect_distribute.argtypes = [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p, i, p]
     L.dtc_roi_align_forward_packed.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, i, i, i, p, i, p]
     L.dtc_roi_align_forward_packed.restype = i
-    L.dtc_roi_align_set_exact.argtypes = [i]
-    L.dtc_roi_align_set_exact.restype = i
     L.dtc_roi_align_workspace_bytes.argtypes = [i]
     L.dtc_roi_align_workspace_bytes.restype = C.c_size_t
     L.dtc_roi_align_forward_packed_ws.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, i, i, i, p, i, p, C.c_size_t, p]
@@ -161,29 +159,6 @@ def make_levels(features, spatial_scales):
         sn, sc, sh, sw = t.stride()
         arr[k] = FeatLevel(t.data_ptr(), t.shape[2], t.shape[3], float(s), 0, sn, sc, sh, sw)
     return arr, ch, dt
-
-
-def roi_align_set_exact(on):
-    """dtc_roi_align_set_exact: True = the sampling_ratio-2 cluster kernel pools with the reference's float32 operations in the
-    reference's order (bit-identical to roi_align_cpu_loop.cpp); False (default) = merged taps for small bins (same value to a
-    few ulps; the contract is 1e-4).  Process-wide, read when a launch is issued (a captured hipGraph keeps its setting).
-    Returns the previous setting; on=None only queries."""
-    return bool(lib().dtc_roi_align_set_exact(-1 if on is None else int(bool(on))))
-
-
-class roi_align_exact:
-    """Context manager: `with hip.roi_align_exact(): ...` issues the enclosed RoIAlign launches in bit-identical mode."""
-
-    def __init__(self, on=True):
-        self.on = on
-
-    def __enter__(self):
-        self.was = roi_align_set_exact(self.on)
-        return self
-
-    def __exit__(self, *exc):
-        roi_align_set_exact(self.was)
-        return False
 
 
 def roi_align_forward(features, spatial_scales, rois, pooled_h, pooled_w, sampling_ratio, roi_levels=None,

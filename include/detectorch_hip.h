@@ -83,15 +83,6 @@ int dtc_roi_align_forward_packed(const dtc_feat_level* levels, int n_levels, int
                                  const float* roi_desc, int n_rois, int pooled_h, int pooled_w, int sampling_ratio, void* out,
                                  int out_dtype, dtc_stream_t stream);
 
-/* Arithmetic of the sampling_ratio == 2 cluster kernel (the FPN box / mask heads on NCHW maps).  Default (0): where a bin's 16
- * bilinear taps fall on at most 4 x 4 pixels they are MERGED -- sum_samples sum_taps w v = sum_r Wy[r] sum_c Wx[c] v[r][c] with
- * the per-row / per-column sums of the axis weights of roi_align_cpu_loop.cpp:92-95 -- 9 or 16 reads and fused multiply-adds
- * per bin instead of 16 reads + 16 weight products + 64 multiplies / adds: the same real number, rounded differently (a few
- * float32 ulps from the reference; the contract is 1e-4).  on = 1: the reference's float32 operations in the reference's order
- * everywhere = bit-identical pooled features (every other RoIAlign kernel of the library always computes that way).
- * Process-wide, read at launch time; on < 0 only queries.  Returns the previous setting.  Environment default: DTC_RA_EXACT=1. */
-int dtc_roi_align_set_exact(int on);
-
 /* dtc_roi_align_forward_packed with a caller-owned workspace (dtc_roi_align_workspace_bytes(n_rois) bytes, 16-byte aligned):
  * lets the map-stationary kernel (the C4 heads) form everything about a RoI that does not depend on the channels -- scaled box,
  * bin sizes, adaptive grid, the axis samples of lib/cppcuda_cffi/src/cpp/roi_align_cpu_loop.cpp:36-95 -- ONCE per launch in a
