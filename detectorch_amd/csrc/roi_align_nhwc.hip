@@ -263,6 +263,8 @@ bool roi_align_nhwc_lds_supported(const RoiAlignParams& p, int in_dtype, int out
   if (bins > kNlMaxBins || p.pooled_h > 16 || p.pooled_w > 16) return false;
   const int cb = in_dtype == DTC_F32 ? 64 : 128;
   if (p.channels % cb != 0) return false;
+  // the tables and the output slab must leave room for a window image (else: the direct-gather kernel)
+  if ((nl_config().lds_kb * 1024 - (1024 + kNlMaxBins * kNlBinRec + cb * bins * 4)) / kNlChunk < 16 + 3) return false;
   for (int l = 0; l < p.n_levels; l++)
     if (p.lv[l].stride_c != 1 || p.lv[l].height > 65535 || p.lv[l].width > 65535) return false;
   const bool f = in_dtype == DTC_F32, h = in_dtype == DTC_F16, b = in_dtype == DTC_BF16;
