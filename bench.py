@@ -319,7 +319,9 @@ def main():
     for _ in range(5):                       # untimed: clocks / caches settle after the step loop above
         for p in paths:                      # every path holds the descriptors of its own inputs from its last step
             p._roi_align_box()
-    torch.cuda.synchronize(dev)
+    # NO synchronisation here: the timed launches queue up behind the warm-up ones, so the first of them does not start on a GPU
+    # that has just gone idle (a launch that follows a device synchronisation was seen to take 1.2-1.4 ms instead of 0.37 in
+    # three of five runs: one such sample moves the mean of 20 by 14 %; min / median / max and every sample are reported too)
     for i in range(iters):
         p = paths[i % NSETS]
         e0[i].record()
@@ -406,6 +408,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k_ms, 4),
                          "launch_ms_min_median_max": [round(float(np.min(k_all)), 4), round(float(np.median(k_all)), 4), round(float(np.max(k_all)), 4)],
+                         "launch_ms_samples": [round(float(v), 4) for v in k_all],
                          "note": ("HBM traffic of this launch == its algorithmic bytes (every feature byte is staged once: map-stationary "
                                   "kernel); what bounds it is the adaptive-grid gather from LDS -- ~5 samples x 4 taps per bin and channel, "
                                   "formed with the reference's unfused multiply-adds -- i.e. VALU issue, not HBM (DESIGN 3.6)") if wl == "cfg2" else

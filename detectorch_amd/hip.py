@@ -93,6 +93,8 @@ def lib():
     L.dtc_postprocess_detections_logits.restype = i
     L.dtc_box_results_nms_limit.argtypes = [p, p, p, i, i, i, f, f, i, p, sz, p, p, p, i, p]
     L.dtc_box_results_nms_limit.restype = i
+    L.dtc_bias_act.argtypes = [p, p, p, i, i, i, i, i, i, i, i, p]
+    L.dtc_bias_act.restype = i
     L.dtc_mask_paste.argtypes = [p, p, i, i, p, p, p, i, i, f, i, p, ll, p, p, p, p, p]
     L.dtc_mask_paste.restype = i
     L.dtc_mask_rle.argtypes = [p, ll, p, p, p, p, i, i, p, i, p, p, i, p, p]
@@ -159,6 +161,40 @@ def make_levels(features, spatial_scales):
         sn, sc, sh, sw = t.stride()
         arr[k] = FeatLevel(t.data_ptr(), t.shape[2], t.shape[3], float(s), 0, sn, sc, sh, sw)
     return arr, ch, dt
+
+
+def bias_act_(x, bias=None, residual=None, relu=True, residual_up2=False):
+    """dtc_bias_act: in place  x = act(x + bias[c] + residual)  on a dense [N,C,H,W] tensor (NCHW-contiguous or channels_last;
+    float32 / float16 / bfloat16).  bias float32 [C]; residual of x's dtype and layout, [N,C,H,W] or -- residual_up2 --
+    [N,C,H/2,W/2] read with nearest x2 upsampling (the FPN top-down sum).  Returns x."""
+    dev = _require_cuda(x, bias, residual)
+    if x.dim() != 4:
+        raise ValueError("x must be [N,C,H,W]")
+    n, c, h, w = x.shape
+    if x.is_contiguous():
+        cl = 0
+    elif x.is_contiguous(memory_format=torch.channels_last):
+        cl = 1
+    else:
+        raise ValueError("x must be dense (NCHW-contiguous or channels_last)")
+    if c == 1 or (h == 1 and w == 1):          # both predicates hold for such shapes: the strides decide nothing, NCHW it is
+        cl = 0 if x.is_contiguous() else 1
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.numel() != c or not bias.is_contiguous():
+            raise ValueError("bias must be a contiguous float32 [C] tensor")
+    if residual is not None:
+        want = (n, c, h // 2, w // 2) if residual_up2 else (n, c, h, w)
+        if tuple(residual.shape) != want or residual.dtype != x.dtype:
+            raise ValueError("residual must be %s of dtype %s" % (want, x.dtype))
+        ok = residual.is_contiguous(memory_format=torch.channels_last) if cl else residual.is_contiguous()
+        if not ok:
+            raise ValueError("residual must have x's memory layout")
+    elif residual_up2:
+        raise ValueError("residual_up2 needs a residual")
+    check(lib().dtc_bias_act(x.data_ptr(), bias.data_ptr() if bias is not None else None,
+                             residual.data_ptr() if residual is not None else None, n, c, h, w, _dtype_code(x.dtype), cl,
+                             1 if relu else 0, 1 if residual_up2 else 0, stream_ptr(dev)), "dtc_bias_act")
+    return x
 
 
 def roi_align_forward(features, spatial_scales, rois, pooled_h, pooled_w, sampling_ratio, roi_levels=None,

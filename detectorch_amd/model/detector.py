@@ -49,13 +49,71 @@ class Bottleneck(nn.Module):
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
+        self.fused = False          # optimize_for_inference(): BatchNorms folded into the convs, shifts in eb1 / eb2 / eb3
+
+    def fold_(self):
+        """Eval-mode BatchNorm (= caffe2 AffineChannel) folded into the preceding bias-free conv: w' = w * g / sqrt(var + eps)
+        per output channel, shift = b - mean * g / sqrt(var + eps) -> float32 epilogue bias (the downsample branch's shift
+        joins bn3's: both are added before the last ReLU)."""
+        b1 = _fold_bn_(self.conv1, self.bn1)
+        b2 = _fold_bn_(self.conv2, self.bn2)
+        b3 = _fold_bn_(self.conv3, self.bn3)
+        if self.downsample is not None:
+            b3 = b3 + _fold_bn_(self.downsample[0], self.downsample[1])
+        self.register_buffer("eb1", b1); self.register_buffer("eb2", b2); self.register_buffer("eb3", b3)
+        self.fused = True
 
     def forward(self, x):
+        if self.fused:      # conv -> one in-place pass (bias, residual, ReLU) instead of BatchNorm, add and ReLU kernels
+            out = hip.bias_act_(self.conv1(x), self.eb1)
+            out = hip.bias_act_(self.conv2(out), self.eb2)
+            idt = x if self.downsample is None else self.downsample[0](x)
+            return hip.bias_act_(self.conv3(out), self.eb3, residual=idt)
         idt = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
         return self.relu(out + idt)
+
+
+@torch.no_grad()
+def _fold_bn_(conv, bn):
+    """Scale conv.weight by the BatchNorm's per-channel factor in place; returns the float32 shift."""
+    g = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+    w = conv.weight.data
+    fmt = torch.channels_last if w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous() else torch.contiguous_format
+    conv.weight.data = (w.float() * g.reshape(-1, 1, 1, 1)).to(w.dtype).contiguous(memory_format=fmt)
+    shift = bn.bias.float() - bn.running_mean.float() * g
+    if conv.bias is not None:
+        shift = shift + conv.bias.float() * g
+        conv.bias = None
+    return shift.contiguous()
+
+
+class _Epilogue(nn.Module):
+    """bias (+ ReLU) of the preceding bias-free conv as one in-place pass (hip.bias_act_)."""
+
+    def __init__(self, bias, relu):
+        super().__init__()
+        self.register_buffer("ebias", bias)
+        self.relu = relu
+
+    def forward(self, x):
+        return hip.bias_act_(x, self.ebias, relu=self.relu)
+
+
+def _conv_nobias(m, x):
+    """m's convolution without its bias (the bias goes into the fused epilogue)."""
+    if isinstance(m, nn.ConvTranspose2d):
+        return F.conv_transpose2d(x, m.weight, None, m.stride, m.padding, m.output_padding, m.groups, m.dilation)
+    return F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
+
+
+def _ebias(m):
+    """float32 copy of m.bias for the epilogue (kept as a buffer: survives .to(dtype) of the parameters only)."""
+    if not hasattr(m, "ebias"):
+        m.register_buffer("ebias", m.bias.detach().float().contiguous())
+    return m.ebias
 
 
 class ResNet(nn.Module):
@@ -96,6 +154,7 @@ class fpn_body(nn.Module):
         self.fpn_output = nn.ModuleList([nn.Conv2d(256, 256, 3, padding=1) for _ in chans])
         self.fpn_indices = [conv_body_layers.index(l) for l in fpn_layers]
         self.fpn_layers = fpn_layers
+        self.fused = False
 
     def forward(self, x):
         lateral = []
@@ -103,6 +162,15 @@ class fpn_body(nn.Module):
             x = self.conv_body[i](x)
             if i in self.fpn_indices:
                 lateral.append(x)
+        if self.fused and all(lateral[i].shape[2] == 2 * lateral[i + 1].shape[2] and lateral[i].shape[3] == 2 * lateral[i + 1].shape[3]
+                              for i in range(len(lateral) - 1)):
+            # lateral 1x1 conv | one pass: + bias + nearest-x2 upsampled level above (detector.py:45-46) | 3x3 conv | + bias
+            n = len(lateral)
+            lat = [None] * n
+            for i in range(n - 1, -1, -1):
+                lat[i] = hip.bias_act_(_conv_nobias(self.fpn_lateral[i], lateral[i]), _ebias(self.fpn_lateral[i]),
+                                       residual=lat[i + 1] if i < n - 1 else None, relu=False, residual_up2=i < n - 1)
+            return [hip.bias_act_(_conv_nobias(self.fpn_output[i], lat[i]), _ebias(self.fpn_output[i]), relu=False) for i in range(n)]
         lateral = [self.fpn_lateral[i](lateral[i]) for i in range(len(lateral))]
         for i in range(len(lateral) - 2, -1, -1):                         # top-down, nearest x2 (detector.py:45-46)
             lateral[i] = F.interpolate(lateral[i + 1], scale_factor=2, mode='nearest') + lateral[i]
@@ -130,9 +198,11 @@ class four_layer_conv(nn.Module):
         self.fcn3 = nn.Conv2d(256, 256, 3, padding=1)
         self.fcn4 = nn.Conv2d(256, 256, 3, padding=1)
 
+    fused = False
+
     def forward(self, x):
         for m in (self.fcn1, self.fcn2, self.fcn3, self.fcn4):
-            x = self.relu(m(x))
+            x = hip.bias_act_(_conv_nobias(m, x), _ebias(m)) if self.fused else self.relu(m(x))
         return x
 
 
@@ -185,7 +255,10 @@ class rpn_head(nn.Module):
     def forward(self, x, logits=False):
         """(rpn_cls_probs, rpn_bbox_pred) as detector.py:123-127; logits=True skips the sigmoid (it is folded into the
         top-k kernel: GenerateProposals(..., scores_are_logits=True))."""
-        c = F.relu(self.conv_rpn(x), inplace=True)
+        if getattr(self, "fused", False):
+            c = hip.bias_act_(_conv_nobias(self.conv_rpn, x), _ebias(self.conv_rpn))
+        else:
+            c = F.relu(self.conv_rpn(x), inplace=True)
         s = self.rpn_cls_prob(c)
         return (s if logits else torch.sigmoid(s)), self.rpn_bbox_pred(c)
 
@@ -279,6 +352,8 @@ class detector(nn.Module):
     @torch.no_grad()
     def forward(self, image, rois=None, scaling_factor=None, roi_original_idx=None):
         h, w = image.size(2), image.size(3)
+        if getattr(self, "_opt_dtype", None) is not None:
+            raise NotImplementedError("a model optimised to a 16-bit type serves through forward_batched()")
         if self.channels_last:
             image = image.contiguous(memory_format=torch.channels_last)
         img_features = self.conv_body(image)
@@ -335,13 +410,70 @@ class detector(nn.Module):
 
     def _head(self, roi_features):
         """conv_head (fc6/fc7 or res5) on pooled features; head_dtype runs it as a low-precision MFMA GEMM, fp32 out."""
-        if self.head_dtype is not None and self.head_dtype != torch.float32:
+        if getattr(self, "_opt_dtype", None) is not None:          # weights already live in the 16-bit type
+            x = self.conv_head(roi_features.to(self._opt_dtype)).float()
+        elif self.head_dtype is not None and self.head_dtype != torch.float32:
             with torch.autocast("cuda", dtype=self.head_dtype):
                 x = self.conv_head(roi_features.to(self.head_dtype))
             x = x.float()
         else:
             x = self.conv_head(roi_features.float() if roi_features.dtype != torch.float32 else roi_features)
         return x.reshape(x.size(0), -1)
+
+    # ---- inference form of the FPN model -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def optimize_for_inference(self, dtype=None):
+        """One-way conversion of an FPN model for serving (forward_batched; forward() too while dtype is float32):
+          * every eval-mode BatchNorm of the ResNet body -- a caffe2 AffineChannel, detector.py:231 -- is folded into its conv
+            (scale into the weights, shift into a float32 epilogue bias);
+          * what follows a convolution -- bias, ReLU, the bottleneck's `+ identity`, the FPN's `upsample(top) + lateral`
+            (detector.py:45-46), the RPN / mask heads' bias + ReLU -- runs as ONE in-place pass (hip.bias_act_) instead of the
+            two to four elementwise kernels of the eager graph;
+          * dtype torch.bfloat16 / float16: the conv / fc6 / fc7 weights are stored once in that type and the body runs in it
+            directly (no autocast: no per-call weight casts); classif_head / bbox_head stay float32 as under autocast.
+        Same function as the unoptimised model up to rounding (float32: the BatchNorm scale is applied to the weights instead
+        of the conv output; 16-bit: one rounding per epilogue instead of one per eager op).  Load weights BEFORE calling this."""
+        if not (self.use_fpn_body and self.use_rpn_head and self.use_two_layer_mlp_head):
+            raise NotImplementedError("optimize_for_inference covers the FPN configurations (e2e_faster/mask_rcnn_R-*-FPN)")
+        if getattr(self, "_optimized", False):
+            raise RuntimeError("model is already in inference form")
+        if dtype not in (None, torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError("dtype must be float32, bfloat16 or float16")
+        if self.training:
+            raise RuntimeError("eval() first: BatchNorm statistics are folded as constants")
+        body = self.conv_body.conv_body                      # nn.Sequential over conv_body_layers
+        mods = list(body)
+        for i, m in enumerate(mods):
+            if isinstance(m, nn.BatchNorm2d):                # stem: conv1 | bn1 | relu  ->  conv1 | bias + ReLU | identity
+                if not (i > 0 and isinstance(mods[i - 1], nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)):
+                    raise NotImplementedError("stem must be conv, bn, relu")
+                body[i] = _Epilogue(_fold_bn_(mods[i - 1], m), relu=True)
+                body[i + 1] = nn.Identity()
+            elif isinstance(m, nn.Sequential):
+                for blk in m:
+                    blk.fold_()
+        self.conv_body.fused = True
+        self.rpn.fused = True
+        heads = [self.conv_body, self.rpn, self.conv_head]
+        if self.use_mask_head:
+            if not isinstance(self.mask_head.conv_head, four_layer_conv):
+                raise NotImplementedError("mask head must be 1up4convs")
+            self.mask_head.conv_head.fused = True
+            heads.append(self.mask_head)
+        for mod in heads:                                    # float32 epilogue biases BEFORE the parameters change type
+            for m in mod.modules():
+                if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and m.bias is not None:
+                    _ebias(m)
+        low = dtype if dtype in (torch.bfloat16, torch.float16) else None
+        if low is not None:
+            for mod in heads:
+                for prm in mod.parameters():                 # parameters only: the epilogue biases (buffers) stay float32
+                    fmt = torch.channels_last if prm.dim() == 4 and self.channels_last else torch.contiguous_format
+                    prm.data = prm.data.to(low).contiguous(memory_format=fmt)
+            self.backbone_dtype = self.head_dtype = low
+        self._optimized, self._opt_dtype = True, low
+        self._paths.clear()
+        return self
 
     # ---- batched entry: B images, zero host round trips ------------------------------------------------------------------
     def _region_path(self, B, h, w, dev):
@@ -381,7 +513,10 @@ class detector(nn.Module):
         low = self.backbone_dtype is not None and self.backbone_dtype != torch.float32
         if low and self.head_dtype not in (None, torch.float32, self.backbone_dtype):
             raise ValueError("backbone_dtype and head_dtype must be the same 16-bit type (RoIAlign does not mix fp16 and bf16)")
-        with (torch.autocast("cuda", dtype=self.backbone_dtype) if low else contextlib.nullcontext()):
+        opt = getattr(self, "_opt_dtype", None)                 # optimize_for_inference(16-bit): weights live in that type
+        if opt is not None:
+            images = images.to(opt)
+        with (torch.autocast("cuda", dtype=self.backbone_dtype) if low and opt is None else contextlib.nullcontext()):
             img_features = self.conv_body(images)
             feats = list(img_features)
             rpn_in = feats + ([F.max_pool2d(feats[-1], 1, stride=2)] if self.fpn_extra_lvl else [])
@@ -404,7 +539,10 @@ class detector(nn.Module):
         path.img_features, path.cls_logits_out, path.bbox_pred_out = img_features, cls_logits, bbox_pred
         if self.use_mask_head:
             mh = self.mask_head
-            if self.head_dtype is not None and self.head_dtype != torch.float32:    # mask-head convs in the pooled features' type
+            if opt is not None:
+                m = hip.bias_act_(_conv_nobias(mh.transposed_conv, mh.conv_head(path.mask_feats.to(opt))), _ebias(mh.transposed_conv))
+                m = mh.classif_logits(m).float()
+            elif self.head_dtype is not None and self.head_dtype != torch.float32:    # mask-head convs in the pooled features' type
                 with torch.autocast("cuda", dtype=self.head_dtype):
                     m = mh.classif_logits(mh.relu(mh.transposed_conv(mh.conv_head(path.mask_feats.to(self.head_dtype)))))
                 m = m.float()

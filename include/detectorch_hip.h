@@ -277,6 +277,20 @@ int dtc_box_voting(const float* top_dets, int n_top, const float* all_dets, int 
                    float* top_dets_out, int32_t* n_voters, dtc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * A10  Convolution epilogue of the inference model (the call sites that carry the path, lib/model/detector.py)
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* x [n,c,h,w] (dense NCHW, or dense channels_last when channels_last != 0; DTC_F32 / DTC_F16 / DTC_BF16), in place:
+ *     x = act( x + bias[c] + residual )        float32 arithmetic, one rounding to x's type
+ * bias float32 [c] or NULL; residual NULL, or a tensor of x's type and layout -- [n,c,h,w], or [n,c,h/2,w/2] read with
+ * nearest-neighbour x2 upsampling when residual_up2 != 0 (h, w even); relu != 0: act = max(., 0) (NaN propagates).
+ * One pass replaces what the reference's graph runs as separate ops after a convolution: the eval-mode BatchNorm /
+ * AffineChannel of the ResNet body (detector.py:231; its scale folded into the weights, its shift = bias) + ReLU, the
+ * bottleneck's `+ identity`, the FPN top-down `upsample(top) + lateral` (detector.py:45-46), the heads' bias + ReLU. */
+int dtc_bias_act(void* x, const float* bias, const void* residual, int n, int c, int h, int w, int dtype,
+                 int channels_last, int relu, int residual_up2, dtc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * (f)-3  Network-input preparation: prep_im_for_blob + im_list_to_blob  (lib/utils/blob.py:62-87, :27-59)
  * --------------------------------------------------------------------------------------------------------------- */
 
