@@ -259,6 +259,13 @@ class rpn_head(nn.Module):
             c = hip.bias_act_(_conv_nobias(self.conv_rpn, x), _ebias(self.conv_rpn))
         else:
             c = F.relu(self.conv_rpn(x), inplace=True)
+        if getattr(self, "fused", False) and logits:
+            # 1x1 heads: bias-free conv, then ONE kernel that adds the float32 bias and writes the float32 NCHW tensor the proposal
+            # kernels read (instead of bias add, widening copy and layout copy)
+            def head(m):
+                y = _conv_nobias(m, c)
+                return torch.add(y, _ebias(m).view(1, -1, 1, 1), out=torch.empty(y.shape, dtype=torch.float32, device=y.device))
+            return head(self.rpn_cls_prob), head(self.rpn_bbox_pred)
         s = self.rpn_cls_prob(c)
         return (s if logits else torch.sigmoid(s)), self.rpn_bbox_pred(c)
 
@@ -508,14 +515,12 @@ class detector(nn.Module):
             raise NotImplementedError("forward_batched covers the FPN configurations (e2e_faster/mask_rcnn_R-*-FPN)")
         B, h, w = images.size(0), images.size(2), images.size(3)
         dev = images.device
-        if self.channels_last:
-            images = images.contiguous(memory_format=torch.channels_last)
+        opt = getattr(self, "_opt_dtype", None)                 # optimize_for_inference(16-bit): weights live in that type
+        # one copy at most: the blob in the body's type and layout
+        images = images.to(dtype=opt or images.dtype, memory_format=torch.channels_last if self.channels_last else torch.preserve_format)
         low = self.backbone_dtype is not None and self.backbone_dtype != torch.float32
         if low and self.head_dtype not in (None, torch.float32, self.backbone_dtype):
             raise ValueError("backbone_dtype and head_dtype must be the same 16-bit type (RoIAlign does not mix fp16 and bf16)")
-        opt = getattr(self, "_opt_dtype", None)                 # optimize_for_inference(16-bit): weights live in that type
-        if opt is not None:
-            images = images.to(opt)
         with (torch.autocast("cuda", dtype=self.backbone_dtype) if low and opt is None else contextlib.nullcontext()):
             img_features = self.conv_body(images)
             feats = list(img_features)

@@ -8,6 +8,7 @@ Times, with HIP events on one MI355X, a Mask R-CNN R-50-FPN `detector` (random w
 import argparse
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -21,8 +22,10 @@ def timed(fn, iters):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
+    h0 = time.perf_counter()
     for _ in range(iters):
         out = fn()
+    timed.host_ms = (time.perf_counter() - h0) * 1e3 / iters        # host time to ISSUE one call (no synchronisation inside)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters, out
@@ -35,6 +38,7 @@ def main():
     ap.add_argument("--batched", action="store_true", help="time detector.forward_batched (backbone -> fused region path -> heads -> detections -> masks, one launch chain, no host round trip) instead of the reference-shaped per-image flow")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--dtype", choices=["fp32", "bf16", "fp16"], default="fp32", help="--batched: backbone_dtype = head_dtype")
+    ap.add_argument("--optimize", action="store_true", help="--batched: detector.optimize_for_inference(dtype) -- BatchNorm folded, fused epilogues, weights stored in the compute type -- instead of autocast")
     a = ap.parse_args()
     from detectorch_amd.model.detector import detector
     from detectorch_amd.utils import result_utils
@@ -48,7 +52,10 @@ def main():
         m = m.to(memory_format=torch.channels_last)
     if a.batched:
         dt = {"fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[a.dtype]
-        m.backbone_dtype = m.head_dtype = dt
+        if a.optimize:
+            m.optimize_for_inference(dt)
+        else:
+            m.backbone_dtype = m.head_dtype = dt
         m.classif_head.weight.data *= 60.0                                  # random weights: make some detections exist
         images = torch.randn(a.batch, 3, 800, 1344, device="cuda")
         sfb = torch.full((a.batch,), 1.6, device="cuda")
@@ -56,14 +63,18 @@ def main():
         with torch.no_grad():
             low = torch.autocast("cuda", dtype=dt) if dt is not None else None
             def body():
+                if a.optimize:
+                    x = images.to(dt) if dt is not None else images
+                    return m.conv_body(x.contiguous(memory_format=torch.channels_last) if a.channels_last else x)
                 if low is None:
                     return m.conv_body(images)
                 with torch.autocast("cuda", dtype=dt):
                     return m.conv_body(images)
             t_body, _ = timed(body, a.iters)
             t_all, path = timed(lambda: m.forward_batched(images, sfb, szb), a.iters)
-        print({"mode": "forward_batched", "batch": a.batch, "dtype": a.dtype, "layout": "NHWC" if a.channels_last else "NCHW",
+        print({"mode": "forward_batched" + (" optimized" if a.optimize else ""), "batch": a.batch, "dtype": a.dtype, "layout": "NHWC" if a.channels_last else "NCHW",
                "backbone_fpn_ms": round(t_body, 3), "forward_batched_ms": round(t_all, 3),
+               "host_issue_ms": round(timed.host_ms, 3),
                "ms_per_image": round(t_all / a.batch, 3), "images_per_sec": round(a.batch / t_all * 1e3, 1),
                "not_backbone_ms_per_image": round((t_all - t_body) / a.batch, 3),
                "detections": path.det_count.tolist()})
