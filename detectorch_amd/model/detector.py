@@ -544,9 +544,13 @@ class detector(nn.Module):
         path.img_features, path.cls_logits_out, path.bbox_pred_out = img_features, cls_logits, bbox_pred
         if self.use_mask_head:
             mh = self.mask_head
+            probs = None
             if opt is not None:
                 m = hip.bias_act_(_conv_nobias(mh.transposed_conv, mh.conv_head(path.mask_feats.to(opt))), _ebias(mh.transposed_conv))
-                m = mh.classif_logits(m).float()
+                # class logits: bias-free 1x1 conv, then bias + widening + NCHW layout in ONE pass, sigmoid in place
+                y = _conv_nobias(mh.classif_logits, m)
+                probs = torch.add(y, _ebias(mh.classif_logits).view(1, -1, 1, 1),
+                                  out=torch.empty(y.shape, dtype=torch.float32, device=dev)).sigmoid_()
             elif self.head_dtype is not None and self.head_dtype != torch.float32:    # mask-head convs in the pooled features' type
                 with torch.autocast("cuda", dtype=self.head_dtype):
                     m = mh.classif_logits(mh.relu(mh.transposed_conv(mh.conv_head(path.mask_feats.to(self.head_dtype)))))
@@ -554,7 +558,7 @@ class detector(nn.Module):
             else:
                 m = mh.conv_head(path.mask_feats.float() if path.mask_feats.dtype != torch.float32 else path.mask_feats)
                 m = mh.classif_logits(mh.relu(mh.transposed_conv(m)))
-            path.bind_masks(torch.sigmoid(m).contiguous())                          # [B*128, 81, 28, 28]
+            path.bind_masks(probs if probs is not None else torch.sigmoid(m).contiguous())     # [B*128, 81, 28, 28]
             path.launch_masks()
         return path
 

@@ -3,7 +3,9 @@
 Times, with HIP events on one MI355X, a Mask R-CNN R-50-FPN `detector` (random weights, eval mode) on a 1x3x800x1344 input:
   backbone+FPN (MIOpen convs, NOT ours) | whole forward = backbone + RPN heads + [GenerateProposals, NMS, collect/distribute,
   RoIAlign]* + box head GEMMs + softmax | postprocess_output* | mask_head = [RoIAlign 14x14]* + 4 convs + deconv | segm_results*
-(* = this repository's kernels).  Usage: python tools/bench_detector.py [--channels-last] [--half] [--iters 10]
+(* = this repository's kernels).  Usage: python tools/bench_detector.py [--channels-last] [--iters 10]
+  --batched [--batch 8] [--dtype fp32|bf16|fp16] [--optimize]: detector.forward_batched on a batch (one launch chain, one sync),
+  under autocast or -- --optimize -- in the inference form of detector.optimize_for_inference (BatchNorm folded, fused epilogues).
 """
 import argparse
 import os

@@ -10,9 +10,10 @@ m = detector(arch='resnet50', conv_body_layers=['conv1', 'bn1', 'relu', 'maxpool
              roi_height=7, roi_width=7, roi_spatial_scale=[0.25, 0.125, 0.0625, 0.03125], roi_sampling_ratio=2,
              use_rpn_head=True, use_mask_head=True, mask_head_type='1up4convs', channels_last=True).cuda()
 m = m.to(memory_format=torch.channels_last)
-m.backbone_dtype = m.head_dtype = torch.bfloat16
 if len(sys.argv) > 1 and sys.argv[1] == "opt":
-    m.optimize_for_inference()
+    m.optimize_for_inference(torch.bfloat16)
+else:
+    m.backbone_dtype = m.head_dtype = torch.bfloat16
 m.classif_head.weight.data *= 60.0
 B = 8
 images = torch.randn(B, 3, 800, 1344, device="cuda")
