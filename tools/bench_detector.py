@@ -40,8 +40,11 @@ def main():
     ap.add_argument("--batched", action="store_true", help="time detector.forward_batched (backbone -> fused region path -> heads -> detections -> masks, one launch chain, no host round trip) instead of the reference-shaped per-image flow")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--dtype", choices=["fp32", "bf16", "fp16"], default="fp32", help="--batched: backbone_dtype = head_dtype")
+    ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True: MIOpen times its solvers per convolution shape on first use (slow first call)")
     ap.add_argument("--optimize", action="store_true", help="--batched: detector.optimize_for_inference(dtype) -- BatchNorm folded, fused epilogues, weights stored in the compute type -- instead of autocast")
     a = ap.parse_args()
+    if a.miopen_benchmark:
+        torch.backends.cudnn.benchmark = True
     from detectorch_amd.model.detector import detector
     from detectorch_amd.utils import result_utils
     from detectorch_amd.utils.multilevel_rois import add_multilevel_rois_for_test

@@ -4,6 +4,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from detectorch_amd.model.detector import detector
 from torch.profiler import profile, ProfilerActivity
+torch.backends.cudnn.benchmark = "bench" in sys.argv
 torch.manual_seed(0)
 m = detector(arch='resnet50', conv_body_layers=['conv1', 'bn1', 'relu', 'maxpool', 'layer1', 'layer2', 'layer3', 'layer4'],
              conv_head_layers='two_layer_mlp', fpn_layers=['layer1', 'layer2', 'layer3', 'layer4'], fpn_extra_lvl=True,
