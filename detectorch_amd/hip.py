@@ -177,8 +177,6 @@ def bias_act_(x, bias=None, residual=None, relu=True, residual_up2=False):
         cl = 1
     else:
         raise ValueError("x must be dense (NCHW-contiguous or channels_last)")
-    if c == 1 or (h == 1 and w == 1):          # both predicates hold for such shapes: the strides decide nothing, NCHW it is
-        cl = 0 if x.is_contiguous() else 1
     if bias is not None:
         if bias.dtype != torch.float32 or bias.numel() != c or not bias.is_contiguous():
             raise ValueError("bias must be a contiguous float32 [C] tensor")
