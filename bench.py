@@ -412,7 +412,10 @@ def main():
                          "note": ("HBM traffic of this launch == its algorithmic bytes (every feature byte is staged once: map-stationary "
                                   "kernel); what bounds it is the adaptive-grid gather from LDS -- ~5 samples x 4 taps per bin and channel, "
                                   "formed with the reference's unfused multiply-adds -- i.e. VALU issue, not HBM (DESIGN 3.6)") if wl == "cfg2" else
-                                 "TCP line-fill rate / EA bandwidth of the re-fetched window rows (DESIGN 3.1)"},
+                                 "bound by the vector L1s' line-fill rate: the cluster kernel fetches every map byte into some L1 once per "
+                                 "cluster that needs it (cfg3: 20.7 M fills = 2.65 GB per launch, 2.3 x the algorithmic bytes) and moves those "
+                                 "fills at ~7.3 TB/s; a pure-load kernel of the same shape reaches 7.8 TB/s from cache / 6.2 TB/s from HBM "
+                                 "(tools/micro/l1_fill_ceiling.hip, DESIGN 3.1)"},
             "consistency": {"timed_region_s": round(dt, 4), "gathered_equals_local": gathered_ok,
                             "gathered_equals_recomputed": recomputed_ok,
                             "sustained": None if dt_sus is None else {"steps": n_sus, "seconds": round(dt_sus, 3),
