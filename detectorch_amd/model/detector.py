@@ -307,6 +307,10 @@ class detector(nn.Module):
         self.N_classes = N_classes
         self._paths = {}               # (B, padded h, padded w, device) -> FpnRegionPath, least recently used first
         self.max_cached_paths = 4
+        # forward_batched: detection rows per image of the fixed-shape results (>= detections_per_im = 100: ties at the image
+        # threshold may exceed it, result_utils.py:161; det_count > max_out signals overflow).  The mask head convolves this many
+        # rows per image whatever the detection count: optimize_for_inference() lowers it to 104.
+        self.max_out = 128
         if train:
             raise NotImplementedError("detectorch_amd.detector is inference-only")
         self.roi_height, self.roi_width = int(roi_height), int(roi_width)
@@ -437,7 +441,8 @@ class detector(nn.Module):
             (detector.py:45-46), the RPN / mask heads' bias + ReLU -- runs as ONE in-place pass (hip.bias_act_) instead of the
             two to four elementwise kernels of the eager graph;
           * dtype torch.bfloat16 / float16: the conv / fc6 / fc7 weights are stored once in that type and the body runs in it
-            directly (no autocast: no per-call weight casts); classif_head / bbox_head stay float32 as under autocast.
+            directly (no autocast: no per-call weight casts); classif_head / bbox_head stay float32 as under autocast;
+          * the fixed-shape results carry 104 instead of 128 detection rows per image (the mask head convolves them all).
         Same function as the unoptimised model up to rounding (float32: the BatchNorm scale is applied to the weights instead
         of the conv output; 16-bit: one rounding per epilogue instead of one per eager op).  Load weights BEFORE calling this."""
         if not (self.use_fpn_body and self.use_rpn_head and self.use_two_layer_mlp_head):
@@ -479,13 +484,14 @@ class detector(nn.Module):
                     prm.data = prm.data.to(low).contiguous(memory_format=fmt)
             self.backbone_dtype = self.head_dtype = low
         self._optimized, self._opt_dtype = True, low
+        self.max_out = 104                                   # 100 detections + room for ties; 19 % fewer mask-head rows than 128
         self._paths.clear()
         return self
 
     # ---- batched entry: B images, zero host round trips ------------------------------------------------------------------
     def _region_path(self, B, h, w, dev):
         from ..pipeline import FpnRegionPath
-        key = (B, h, w, str(dev))
+        key = (B, h, w, str(dev), self.max_out)
         if key in self._paths:
             self._paths[key] = self._paths.pop(key)          # most recently used last
         else:
@@ -496,7 +502,7 @@ class detector(nn.Module):
                 self._paths.pop(next(iter(self._paths)))
             self._paths[key] = FpnRegionPath(B, dev, channels=256, n_cls=self.N_classes, pad_h=h, pad_w=w, cls_logits=True,
                                              with_rle=self.use_mask_head, box_pooled=self.roi_height, mask_pooled=14,
-                                             sampling_ratio=self.roi_sampling_ratio,
+                                             sampling_ratio=self.roi_sampling_ratio, max_out=self.max_out,
                                              feat_dtype=self.head_dtype or torch.float32)
         return self._paths[key]
 
