@@ -551,16 +551,17 @@ template <> __device__ __forceinline__ float hi16_to_f32<bf16_t>(uint32_t w) { r
 template <> __device__ __forceinline__ float lo16_to_f32<float>(uint32_t w) { return 0.f; }      // never instantiated for float maps
 template <> __device__ __forceinline__ float hi16_to_f32<float>(uint32_t w) { return 0.f; }
 
-template <typename TIn, typename TOut>
+// CB: channels per workgroup (64; 32 for 16-bit maps with more than 64 bins, whose [CB][bins] float32 slab would otherwise take 50 KB)
+template <typename TIn, typename TOut, int CB>
 __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   AxisEntry* ytab = reinterpret_cast<AxisEntry*>(smem);
   float* slab = reinterpret_cast<float*>(smem) + kLdsTableFloats;
-  const int nct = ceil_div(p.channels, 64);
+  const int nct = ceil_div(p.channels, CB);
   const int wi = xcd_work_item(blockIdx.x, gridDim.x, p.xcd_remap);
   const int ri = wi / nct;
-  const int c0 = (wi - ri * nct) * 64;
-  const int nc = min(64, p.channels - c0);
+  const int c0 = (wi - ri * nct) * CB;
+  const int nc = min(CB, p.channels - c0);
   const int bins = p.pooled_h * p.pooled_w;
   const int tid = threadIdx.x;
   const RoiHead hd = load_roi_head(p, ri);
@@ -590,10 +591,11 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
     // 16-bit maps, 2 x 2 sampling grid, a full 64-channel block: lane <-> (8 channels = one 16-byte load per tap, bin slot of 32):
     // a 7 x 7 RoI takes TWO rounds of 16 loads in flight per lane where the 4-channel mapping below takes four -- the kernel is
     // bound by those dependent L1 / L2 round trips, not by bytes (0.32 -> 0.2x ms per 8000-RoI launch).  Same arithmetic, same order.
-    const bool wide = nc == 64 && tab_ok && gh == 2 && gw == 2 && ((L.stride_h | L.stride_w | L.stride_n) & 7) == 0 &&
+    const bool wide = nc == CB && tab_ok && gh == 2 && gw == 2 && ((L.stride_h | L.stride_w | L.stride_n) & 7) == 0 &&
                       (reinterpret_cast<uintptr_t>(L.data) & 15) == 0 && inv_count != 0.f;
     if (wide) {
-      const int q8 = tid & 7, slot8 = tid >> 3;
+      constexpr int NQ8 = CB / 8;
+      const int q8 = tid % NQ8, slot8 = tid / NQ8;
       const TIn* base8 = reinterpret_cast<const TIn*>(L.data) + (int64_t)b * L.stride_n + c0 + 8 * q8;
       auto ld = [&](int yo, int xo) { return *reinterpret_cast<const uint4*>(base8 + yo + xo); };
       auto taps = [&](int bin, uint4* t, AxisEntry* ax) {          // ax: y0 y1 x0 x1 of the bin
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
       };
       // (requesting the taps of both bins of a lane before pooling either -- one round trip per workgroup, 160 VGPRs, three waves per
       //  SIMD -- was measured slower: 0.274 ms against 0.242 for the box-head launch)
-      for (int bin = slot8; bin < bins; bin += kRoiAlignThreads / 8) {
+      for (int bin = slot8; bin < bins; bin += kRoiAlignThreads / NQ8) {
         uint4 t[16];
         AxisEntry ax[4];
         taps(bin, t, ax);
@@ -642,13 +644,14 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
       return;
     }
   }
-  const int q = tid & 15, slot = tid >> 4;
+  constexpr int NQ4 = CB / 4;
+  const int q = tid % NQ4, slot = tid / NQ4;
   const TIn* base = reinterpret_cast<const TIn*>(L.data) + (int64_t)b * L.stride_n + c0 + 4 * q;
   const bool full = (4 * q + 3) < nc;                       // this lane's 4 channels all exist
   const bool vec = full && ((L.stride_h | L.stride_w | L.stride_n) & 3) == 0 && ((c0 & 3) == 0) &&
                    (reinterpret_cast<uintptr_t>(L.data) & 15) == 0;
   if (4 * q < nc) {
-    for (int bin = slot; bin < bins; bin += kRoiAlignThreads / 16) {
+    for (int bin = slot; bin < bins; bin += kRoiAlignThreads / NQ4) {
       const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       if (vec && tab_ok && gh == 2 && gw == 2) {
@@ -728,6 +731,7 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
 struct RoiAlignConfig {
   bool tile = true, map = true, general = false, nhwc_direct = true, xcd = true, cts64 = true;
   int ch_block = 0, lds_bytes = 52 * 1024;
+  int nhwc_wide16 = 1;        // DTC_RA_NHWC_WIDE16=0: 16-bit channels_last maps with > 64 bins go back to the LDS kernel (A/B)
 };
 static const RoiAlignConfig& roi_align_config() {
   static const RoiAlignConfig cfg = [] {
@@ -738,6 +742,7 @@ static const RoiAlignConfig& roi_align_config() {
     c.nhwc_direct = getenv("DTC_ROIALIGN_NO_NHWC_DIRECT") == nullptr;
     c.xcd = getenv("DTC_RA_NO_XCD") == nullptr;
     c.cts64 = getenv("DTC_RA_NO_CTS64") == nullptr;      // 64-channel sub-tiles for windows <= 128 px: +4 % on the bench workload
+    if (const char* e = getenv("DTC_RA_NHWC_WIDE16")) c.nhwc_wide16 = atoi(e) != 0;
     if (const char* e = getenv("DTC_RA_CHBLOCK")) { const int v = atoi(e); if (v >= 64 && v % 64 == 0) c.ch_block = v; }
     if (const char* e = getenv("DTC_ROIALIGN_LDS_KB")) { const int v = atoi(e); if (v >= 16 && v <= 160) c.lds_bytes = v * 1024; }
     return c;
@@ -745,19 +750,26 @@ static const RoiAlignConfig& roi_align_config() {
   return cfg;
 }
 
+template <typename TIn, typename TOut, int CB>
+static int launch_nhwc_cb(const RoiAlignParams& p, hipStream_t stream) {
+  const size_t smem = (size_t)kLdsTableFloats * 4 + (size_t)CB * p.pooled_h * p.pooled_w * 4 + 16;
+  static std::once_flag once;
+  static hipError_t rc = hipSuccess;
+  std::call_once(once, [] { rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_nhwc<TIn, TOut, CB>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+  if (rc != hipSuccess) return DTC_ELAUNCH;
+  const int nct = ceil_div(p.channels, CB);
+  hipLaunchKernelGGL((roi_align_fwd_nhwc<TIn, TOut, CB>), dim3((unsigned)p.n_rois * nct), dim3(kRoiAlignThreads), smem, stream, p);
+  DTC_CHECK_LAUNCH();
+  return DTC_OK;
+}
+
 template <typename TIn, typename TOut>
 static int launch_nhwc(const RoiAlignParams& p, hipStream_t stream) {
   if (p.n_rois == 0) return DTC_OK;
-  const size_t smem = (size_t)kLdsTableFloats * 4 + (size_t)64 * p.pooled_h * p.pooled_w * 4 + 16;
-  static std::once_flag once;
-  static hipError_t rc = hipSuccess;
-  std::call_once(once, [] { rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_nhwc<TIn, TOut>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-  if (rc != hipSuccess) return DTC_ELAUNCH;
-  const int nct = ceil_div(p.channels, 64);
-  hipLaunchKernelGGL((roi_align_fwd_nhwc<TIn, TOut>), dim3((unsigned)p.n_rois * nct), dim3(kRoiAlignThreads), smem, stream, p);
-  DTC_CHECK_LAUNCH();
-  return DTC_OK;
+  // 16-bit maps with more than 64 bins (the 14 x 14 mask head): 32-channel blocks, so that the [CB][bins] float32 slab stays at 25 KB
+  if (sizeof(TIn) == 2 && p.pooled_h * p.pooled_w > 64 && p.channels % 32 == 0) return launch_nhwc_cb<TIn, TOut, 32>(p, stream);
+  return launch_nhwc_cb<TIn, TOut, 64>(p, stream);
 }
 
 template <typename TIn, typename TOut>
@@ -846,7 +858,9 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   // channels_last, sampling_ratio 2, <= 64 bins: window staged with LDS-DMA, conflict-free tap reads (roi_align_nhwc.hip)
   if (all_nhwc && !cfg.general && cfg.nhwc_direct && dtc::roi_align_nhwc_lds_supported(p, in_dtype, out_dtype))
     return dtc::launch_roi_align_nhwc_lds(p, in_dtype, out_dtype, s);
-  if (lds_ok && all_nhwc && few_taps && cfg.nhwc_direct) return dtc::launch_typed(dtc::kKernNhwc, p, in_dtype, out_dtype, s);
+  // 16-bit channels_last maps, 2 x 2 samples: the direct kernel's 8-channel lanes (16-byte tap loads) for every bin count
+  const bool wide16 = in_dtype != DTC_F32 && sampling_ratio == 2 && channels % 32 == 0 && cfg.nhwc_wide16;
+  if (lds_ok && all_nhwc && (few_taps || wide16) && cfg.nhwc_direct) return dtc::launch_typed(dtc::kKernNhwc, p, in_dtype, out_dtype, s);
   // one level whose whole map fits LDS (the C4 heads), adaptive sampling: the map-stationary kernel (roi_align_map.hip)
   if (cfg.map && !cfg.general && sampling_ratio != 2 && dtc::roi_align_map_supported(p, in_dtype, out_dtype))
     return dtc::launch_roi_align_map_ws(p, in_dtype, out_dtype, workspace, workspace_bytes, s);

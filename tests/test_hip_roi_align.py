@@ -403,6 +403,27 @@ def _nhwc_case(oracle, C, seed, R=260):
     return feats, rois5, lv
 
 
+@pytest.mark.parametrize("dtype,C,ph", [("f16", 96, 14), ("bf16", 64, 14), ("bf16", 160, 7), ("f16", 72, 14)])
+def test_nhwc_16bit_direct_kernel_wide_lanes_vs_oracle(hip, oracle, dtype, C, ph):
+    """channels_last 16-bit maps, sampling ratio 2: the direct-gather kernel with 8 channels per lane (16-byte tap loads) -- 64-channel
+    blocks for 7x7 bins, 32-channel blocks for the 14x14 bins of the mask head; C = 160 / 72 leave a partial last block on the
+    4-channel lanes (72 is not a multiple of 32 at 14x14: the LDS kernel takes it).  Small, large and border boxes on all four
+    levels: bit-exact against the oracle on the up-cast maps; the 16-bit output is that result rounded once."""
+    feats, rois5, lv = _nhwc_case(oracle, C, C + ph, R=120)
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    tf = [cu(f).to(tdt).contiguous(memory_format=torch.channels_last) for f in feats]
+    up = [t.float().contiguous().cpu().numpy() for t in tf]
+    ref = np.zeros((rois5.shape[0], C, ph, ph), np.float32)
+    for l in range(4):
+        m = lv == l
+        if m.any():
+            ref[m] = oracle.roi_align_forward(up[l], rois5[m], ph, ph, synth.FPN_ROI_SCALES[l], 2)
+    out = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, cu(rois5), ph, ph, 2, roi_levels=cu(lv))
+    assert out.dtype == torch.float32 and np.array_equal(out.cpu().numpy(), ref)
+    out16 = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, cu(rois5), ph, ph, 2, roi_levels=cu(lv), out_dtype=tdt)
+    assert torch.equal(out16.cpu(), torch.from_numpy(ref).to(tdt))
+
+
 @pytest.mark.parametrize("dtype,C", [("f32", 64), ("f32", 256), ("f16", 128), ("bf16", 256)])
 def test_nhwc_lds_dma_kernel_vs_oracle(hip, oracle, dtype, C):
     """channels_last feature maps, 7x7 bins, sampling ratio 2: window staged with LDS-DMA, lane <-> channel chunk.  Small boxes
