@@ -81,19 +81,24 @@ def _boost(model, k=60.0):
     return model
 
 
-def test_forward_batched_equals_reference_shaped_forward():
+@pytest.mark.parametrize("optimized", [False, True])
+def test_forward_batched_equals_reference_shaped_forward(optimized):
     """detector.forward_batched (backbone(B) -> FpnRegionPath stages -> heads -> detections -> mask branch, no host round
     trip) against the reference-shaped batch-1 calls: forward() + postprocess_output + add_multilevel_rois_for_test +
-    mask_head + segm_results (eval_mask_FPN.ipynb cells 4, 6)."""
+    mask_head + segm_results (eval_mask_FPN.ipynb cells 4, 6).  optimized: the same on the float32 inference form of the model
+    (optimize_for_inference: BatchNorm folded, fused epilogues, 104 detection rows per image) -- both flows run the fused modules."""
     from detectorch_amd.model.detector import detector
     from detectorch_amd.utils import result_utils
     from detectorch_amd.utils.multilevel_rois import add_multilevel_rois_for_test
     model = _boost(_fpn_model())
+    if optimized:
+        model.optimize_for_inference()
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     image = torch.randn(1, 3, 320, 448, generator=g, device="cuda")
     sf, im_size = torch.tensor([1.6], device="cuda"), torch.tensor([[200.0, 280.0]], device="cuda")
     path = model.forward_batched(image, sf, im_size)
     torch.cuda.synchronize()
+    assert path.max_out == (104 if optimized else 128)
     cls_b, bbox_b, rois_b, feats_b = detector.per_image(path, 0)
     cls_score, bbox_pred, rois, feats = model(image, scaling_factor=sf)
     # two passes through MIOpen's convs are not bit-reproducible (algorithm selection warms up): same proposals up to conv rounding
