@@ -367,10 +367,11 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from kernel_hash import kernel_sha16
             stamped = tj.get(key + "_detail", {}).get("kernel_sha16")
-            if stamped == kernel_sha16(wl):      # the counters were collected on THIS kernel source
+            running = kernel_sha16(wl, channels_last=a.channels_last)
+            if stamped == running:               # the counters were collected on THIS kernel source
                 traffic, traffic_src = tj[key], "profiles/roialign_traffic.json[%s] (rocprofv3 --pmc TCC_EA0_* passes, tools/collect_profiles.sh; not measured in this run; kernel source hash %s matches)" % (key, stamped)
             else:
-                traffic_src = "profiles/roialign_traffic.json[%s] is stale: collected on kernel source %s, running %s" % (key, stamped, kernel_sha16(wl))
+                traffic_src = "profiles/roialign_traffic.json[%s] is stale: collected on kernel source %s, running %s" % (key, stamped, running)
     except Exception:
         pass
 

@@ -42,14 +42,16 @@ import os, sys
 sys.path.insert(0, "tools")
 from kernel_hash import kernel_sha16
 wl = "cfg3"
-for tok in os.environ.get("BENCH_ARGS", "").split():
+toks = os.environ.get("BENCH_ARGS", "").split()
+for tok in toks:
     if tok in ("cfg2", "cfg3", "cfg5"): wl = tok
+nhwc, f16 = "--channels-last" in toks, ("--fp16" in toks or wl == "cfg5")
 if res:
     g = max(res, key=lambda k: int(k))
-    key = "%s_b8_nchw_%s" % (wl, "f16" if wl == "cfg5" else "f32")
+    key = "%s_b8_%s_%s" % (wl, "nhwc" if nhwc else "nchw", "f16" if f16 else "f32")
     entry = {key: int(res[g]["read_bytes"] + res[g]["write_bytes"]),
              key + "_detail": {"grid": int(g), "read_bytes": int(res[g]["read_bytes"]), "write_bytes": int(res[g]["write_bytes"]),
-                               "kernel_sha16": kernel_sha16(wl), "source": "profiles/<round>_roialign_%s_pmc_raw.json" % wl}}
+                               "kernel_sha16": kernel_sha16(wl, channels_last=nhwc), "source": "profiles/<round>_roialign_%s_pmc_raw.json" % wl}}
     json.dump(entry, open(out + "/traffic_entry.json", "w"), indent=1)
 # the box-head launch is the one with the largest grid; bench.py reports its read + write bytes as roofline.traffic
 if res:

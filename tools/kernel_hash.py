@@ -19,12 +19,16 @@ def strip(src):
     return re.sub(r"\s+", " ", src).strip()
 
 
-def kernel_sha16(workload):
+# channels_last feature maps (bench.py --channels-last) are pooled by the kernels of these files whatever the workload
+NHWC_FILES = ["roi_align.hip", "roi_align_nhwc.hip", "roi_align_common.h"]
+
+
+def kernel_sha16(workload, channels_last=False):
     h = hashlib.sha256()
-    for f in KERNEL_FILES[workload]:
+    for f in (NHWC_FILES if channels_last else KERNEL_FILES[workload]):
         h.update(strip(open(os.path.join(CSRC, f)).read()).encode())
     return h.hexdigest()[:16]
 
 
 if __name__ == "__main__":
-    print(kernel_sha16(sys.argv[1] if len(sys.argv) > 1 else "cfg3"))
+    print(kernel_sha16(sys.argv[1] if len(sys.argv) > 1 else "cfg3", channels_last="nhwc" in sys.argv[2:]))
