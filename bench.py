@@ -359,7 +359,7 @@ def main():
         if not recomputed_ok:
             raise SystemExit("detections gathered from another rank differ from their recomputation on rank 0")
 
-    traffic, traffic_src = None, None
+    traffic, traffic_src, l1_fills = None, None, None
     try:   # HBM-side bytes per launch of the same kernel/config: rocprofv3 --pmc passes, committed (profiles/README.md)
         tj = json.load(open(os.path.join(ROOT, "profiles", "roialign_traffic.json")))
         key = "%s_b%d_%s_%s" % (wl, a.batch, "nhwc" if a.channels_last else "nchw", "f16" if fp16 else "f32")
@@ -368,6 +368,14 @@ def main():
             from kernel_hash import kernel_sha16
             stamped = tj.get(key + "_detail", {}).get("kernel_sha16")
             running = kernel_sha16(wl, channels_last=a.channels_last)
+            if stamped == running and "l1_fill_requests" in tj.get(key + "_detail", {}):
+                # the vector L1s' line fills of this launch (TCP -> TCC read requests x 128 B, same counter run) against the rate a
+                # kernel that ONLY loads reaches with this kernel's workgroup shape and load pattern (tools/micro/l1_fill_ceiling.hip)
+                nreq = int(tj[key + "_detail"]["l1_fill_requests"])
+                l1_fills = {"requests_per_launch": nreq, "bytes_per_launch": nreq * 128,
+                            "rate_TBps": round(nreq * 128 / (k_ms * 1e-3) / 1e12, 2),
+                            "pure_load_kernel_TBps": {"from_cache": 7.83, "from_hbm": 6.16},
+                            "source": tj[key + "_detail"].get("l1_fill_source")}
             if stamped == running:               # the counters were collected on THIS kernel source
                 traffic, traffic_src = tj[key], "profiles/roialign_traffic.json[%s] (rocprofv3 --pmc TCC_EA0_* passes, tools/collect_profiles.sh; not measured in this run; kernel source hash %s matches)" % (key, stamped)
             else:
@@ -410,6 +418,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k_ms, 4),
                          "launch_ms_min_median_max": [round(float(np.min(k_all)), 4), round(float(np.median(k_all)), 4), round(float(np.max(k_all)), 4)],
                          "launch_ms_samples": [round(float(v), 4) for v in k_all],
+                         "l1_fills": l1_fills,
                          "note": ("HBM traffic of this launch == its algorithmic bytes (every feature byte is staged once: map-stationary "
                                   "kernel); what bounds it is the adaptive-grid gather from LDS -- ~5 samples x 4 taps per bin and channel, "
                                   "formed with the reference's unfused multiply-adds -- i.e. VALU issue, not HBM (DESIGN 3.6)") if wl == "cfg2" else
