@@ -5,8 +5,10 @@
 // instruction fetches 16 ROW PIECES of 64 B (4 lanes x 16 B) from 16 different rows of a "feature plane" whose rows are
 // `pitch` bytes apart, i.e. a patch of a window; a thread keeps U such loads in flight, a workgroup sweeps `rows` x 128 B
 // patches over its own channel planes.  Nothing is computed: the loaded values are summed into one store per thread.
-// Variants: working set resident in L2 + Infinity Cache (64 MB region) / streaming from HBM (2 GB region); contiguous 1-KB
-// wave loads for comparison (the plain streaming-copy read pattern).
+// Variants: working set resident in the Infinity Cache (64 MB region: 2 x the aggregate L2, so nearly every fill MISSES L2 -- a
+// MALL -> L2 -> L1 rate) / streaming from HBM (2 GB region) / **L2-resident** (round 4: every XCD's workgroups -- block b runs on
+// XCD b % 8 -- walk a slice of 1-3 MB of their own, i.e. every fill after the first sweep hits that XCD's 4 MB L2: the rate an
+// L1 can pull from a HITTING L2); contiguous 1-KB wave loads for comparison (the plain streaming-copy read pattern).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,10 +18,12 @@
 // MODE 0: patch rows (16 rows x 64 B per wave instruction).  MODE 1: 1 KB contiguous per wave instruction.
 template <int MODE, int U>
 __global__ __launch_bounds__(256) void fill_kernel(const float4* __restrict__ src, size_t region_f4, int pitch_f4, int iters,
-                                                   float* __restrict__ sink) {
+                                                   float* __restrict__ sink, int per_xcd) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t wg = blockIdx.x;
   float acc = 0.f;
+  // per_xcd: region_f4 is the size of ONE XCD's private slice; the workgroups of XCD x (= blockIdx % 8) stay inside slice x
+  if (per_xcd) src += (size_t)(blockIdx.x % 8) * region_f4;
   // every workgroup starts somewhere else in the region and walks it with a large odd stride: no two workgroups share lines
   size_t pos = ((wg * 0x9E3779B97F4A7C15ull) % region_f4) & ~(size_t)7;      // 128-byte aligned: a 256-byte row strip = 2 lines
   for (int it = 0; it < iters; it++) {
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256) void fill_kernel(const float4* __restrict__ sr
 }
 
 template <int MODE, int U>
-static int run(const char* name, const float4* src, size_t region_bytes, int pitch_bytes, int wgs_per_cu, float* sink) {
+static int run(const char* name, const float4* src, size_t region_bytes, int pitch_bytes, int wgs_per_cu, float* sink, int per_xcd = 0) {
   const int cus = 256, blocks = cus * wgs_per_cu * 8, iters = 64;
   const size_t region_f4 = region_bytes / 16;
   hipEvent_t e0, e1;
@@ -54,11 +58,11 @@ static int run(const char* name, const float4* src, size_t region_bytes, int pit
   // occupancy is set through the dynamic LDS request: 160 KB / wgs_per_cu
   const size_t lds = (size_t)(160 * 1024 / wgs_per_cu) - 1024;
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fill_kernel<MODE, U>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  for (int w = 0; w < 2; w++) hipLaunchKernelGGL((fill_kernel<MODE, U>), dim3(blocks), dim3(256), lds, 0, src, region_f4, pitch_bytes / 16, iters, sink);
+  for (int w = 0; w < 2; w++) hipLaunchKernelGGL((fill_kernel<MODE, U>), dim3(blocks), dim3(256), lds, 0, src, region_f4, pitch_bytes / 16, iters, sink, per_xcd);
   CHECK(hipDeviceSynchronize());
   CHECK(hipEventRecord(e0));
   const int reps = 5;
-  for (int r = 0; r < reps; r++) hipLaunchKernelGGL((fill_kernel<MODE, U>), dim3(blocks), dim3(256), lds, 0, src, region_f4, pitch_bytes / 16, iters, sink);
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL((fill_kernel<MODE, U>), dim3(blocks), dim3(256), lds, 0, src, region_f4, pitch_bytes / 16, iters, sink, per_xcd);
   CHECK(hipEventRecord(e1));
   CHECK(hipDeviceSynchronize());
   float ms = 0.f;
@@ -91,5 +95,13 @@ int main() {
   if (run<0, 4>("patch rows, 4 loads in flight per thread, from HBM", src, big, pitch, 3, sink)) return 1;
   if (run<1, 8>("contiguous, 8 workgroups/CU, from HBM", src, big, pitch, 8, sink)) return 1;
   if (run<1, 8>("contiguous, 8 workgroups/CU, cache-resident", src, (size_t)64 << 20, pitch, 8, sink)) return 1;
+  // round 4: L2-RESIDENT -- each XCD's workgroups confined to their own slice (the slice is swept ~25-75 times per launch)
+  for (int mb = 1; mb <= 3; mb++) {
+    if (run<0, 8>("patch rows, L2-resident (per-XCD slice)", src, (size_t)mb << 20, pitch, 3, sink, 1)) return 1;
+    if (run<1, 8>("contiguous 1 KB, L2-resident (per-XCD slice)", src, (size_t)mb << 20, pitch, 3, sink, 1)) return 1;
+  }
+  if (run<0, 8>("patch rows, L2-resident (per-XCD slice), 4 workgroups/CU", src, (size_t)2 << 20, pitch, 4, sink, 1)) return 1;
+  if (run<0, 4>("patch rows, L2-resident, 4 loads in flight", src, (size_t)2 << 20, pitch, 3, sink, 1)) return 1;
+  if (run<0, 8>("patch rows, 8 MB per XCD (2 x L2: Infinity Cache)", src, (size_t)8 << 20, pitch, 3, sink, 1)) return 1;
   return 0;
 }
