@@ -669,18 +669,23 @@ namespace dtc {
 #endif
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
-// Float32 output -> the pipelined kernel (two 512-thread workgroups per CU, 78 KB each: two 132-pixel images for float32 maps).
-// 16-bit output -> roi_align_fwd_nhwc_lds (four 256-thread workgroups per CU at 40 KB: measured on MI355X, 8000 RoIs x 256 ch, float32:
-// 32 KB 0.478 ms, 36 0.429, 40 0.401, 46 0.440, 52 0.419, 60 0.509, 78 0.494, 104-156 0.82).
-// Development / A-B knobs, resolved once per process: DTC_RA_NHWC_LDS=0 (neither kernel), DTC_RA_NHWC_LDS_KB, DTC_RA_NHWC_PIPE=0 (the
-// round-3 kernel for every output type), DTC_RA_NHWC_PIPE16=1 / DTC_RA_NHWC_LDS_16BIT=1 (16-bit maps too), DTC_RA_NHWC_WGS.
+// Which kernel (measured on MI355X, bench inputs, batch 8, float32 maps; profiles/r04_c_*):
+//   <= 64 bins (box head)   roi_align_fwd_nhwc_lds (four 256-thread workgroups per CU at 40 KB).  The pipelined kernel is 7-11 % faster
+//                           on the bench's RoIs (0.349 against 0.36-0.39 ms per 8000-RoI launch) but 45 % SLOWER on the harder set
+//                           (log-uniform sides 16-600 px: 0.58 against 0.40 ms) -- large windows become many small units, each with
+//                           the pipeline's fixed cost and a quarter of the bin slots busy -- so it is NOT the default there;
+//   > 64 bins (mask head)   the pipelined kernel (two 512-thread workgroups per CU, 78 KB each: two 132-pixel images): 0.129 ms per
+//                           1024-RoI launch against 0.180 for the RoI-stationary LDS kernel (roi_align.hip) that took these before.
+// Float32 output only for the pipelined kernel.  Development / A-B knobs, resolved once per process: DTC_RA_NHWC_LDS=0 (neither
+// kernel), DTC_RA_NHWC_LDS_KB, DTC_RA_NHWC_PIPE = 0 never / 1 by bin count (default) / 2 always, DTC_RA_NHWC_PIPE16=1 /
+// DTC_RA_NHWC_LDS_16BIT=1 (16-bit maps too), DTC_RA_NHWC_WGS.
 struct NlConfig { int enabled = 1, lds_kb = 0, pipe = 1, pipe16 = 0, wgs = 0; };
 static const NlConfig& nl_config() {
   static const NlConfig cfg = [] {
     NlConfig c;
     if (const char* e = getenv("DTC_RA_NHWC_LDS")) c.enabled = atoi(e) != 0;
     if (const char* e = getenv("DTC_RA_NHWC_LDS_KB")) { const int v = atoi(e); if (v >= 24 && v <= 160) c.lds_kb = v; }
-    if (const char* e = getenv("DTC_RA_NHWC_PIPE")) c.pipe = atoi(e) != 0;
+    if (const char* e = getenv("DTC_RA_NHWC_PIPE")) { const int v = atoi(e); if (v >= 0 && v <= 2) c.pipe = v; }
     if (const char* e = getenv("DTC_RA_NHWC_PIPE16")) c.pipe16 = atoi(e) != 0;
     if (const char* e = getenv("DTC_RA_NHWC_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 8) c.wgs = v; }
     return c;
@@ -704,9 +709,9 @@ static bool np_plan(int in_dtype, NpPlan& pl) {
   if (pl.wgs_per_cu < 1) pl.wgs_per_cu = 1;
   return pl.img_pixels >= 16;
 }
-static bool np_takes(int in_dtype, int out_dtype) {
+static bool np_takes(int bins, int in_dtype, int out_dtype) {
   const NlConfig& cfg = nl_config();
-  return cfg.pipe && out_dtype == DTC_F32 && (in_dtype == DTC_F32 || cfg.pipe16);
+  return (cfg.pipe == 2 || (cfg.pipe == 1 && bins > kNlMaxBins)) && out_dtype == DTC_F32 && (in_dtype == DTC_F32 || cfg.pipe16);
 }
 
 bool roi_align_nhwc_lds_supported(const RoiAlignParams& p, int in_dtype, int out_dtype) {
@@ -719,7 +724,7 @@ bool roi_align_nhwc_lds_supported(const RoiAlignParams& p, int in_dtype, int out
   if (p.pooled_h > 16 || p.pooled_w > 16) return false;
   const int cb = in_dtype == DTC_F32 ? 64 : 128;
   if (p.channels % cb != 0) return false;
-  if (np_takes(in_dtype, out_dtype)) { NpPlan pl; if (!np_plan(in_dtype, pl)) return false; }
+  if (np_takes(bins, in_dtype, out_dtype)) { NpPlan pl; if (!np_plan(in_dtype, pl)) return false; }
   // the round-3 kernel: <= 64 bins; the tables and the output slab must leave room for a window image (else: the direct-gather kernel)
   else if (bins > kNlMaxBins || ((cfg.lds_kb ? cfg.lds_kb : 40) * 1024 - (1024 + kNlMaxBins * kNlBinRec + cb * bins * 4)) / kNlChunk < 16 + 3) return false;
   for (int l = 0; l < p.n_levels; l++)
@@ -792,7 +797,7 @@ static int launch_nl_t(const RoiAlignParams& p, hipStream_t stream) {
 
 int launch_roi_align_nhwc_lds(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream) {
   if (p.n_rois == 0) return DTC_OK;
-  if (np_takes(in_dtype, out_dtype)) {
+  if (np_takes(p.pooled_h * p.pooled_w, in_dtype, out_dtype)) {
     if (in_dtype == DTC_F32) return launch_np_t<float>(p, in_dtype, stream);
     if (in_dtype == DTC_F16) return launch_np_t<__half>(p, in_dtype, stream);
     if (in_dtype == DTC_BF16) return launch_np_t<bf16_t>(p, in_dtype, stream);

@@ -150,7 +150,7 @@ struct TileGeom {            // one cluster, all uniform
 template <typename TIn, typename TOut, int NT>
 __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_feat_level& L, const TIn* fbase, int c0, int nc,
                                             int bins, float* slab, float* win, const TileRoi* troi, const TileGeom& g,
-                                            const TileItem& it, int rl, int bin, int phase_t, TileTrace& tt) {
+                                            const TileItem& it, int rl, int bin, TileTrace& tt) {
   constexpr int NW = NT / 64;
   constexpr int U = TileShape<NT>::kUnits;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, cl = (lane >> 4) & 3;
@@ -260,29 +260,19 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
   };
 
   TT_MARK(3);
-  // Pass order.  Default: channel quads front to back.  phase_t > 0 (development knob DTC_RA_TILE_PHASE_T, units of 10 ns): cyclic,
-  // starting at the pass the wall clock names, so that the workgroups resident on an XCD stage the SAME channels at about the same
-  // time whenever they started (their patches then meet in that XCD's L2).
-  const int npass = nq_tot / nq_pass;
-  int pi0 = 0;
-  if (phase_t > 0) pi0 = (int)((__builtin_amdgcn_s_memrealtime() / (unsigned long long)phase_t) % (unsigned long long)npass);
-  pi0 = uni(pi0);
-  if (vec) issue(4 * pi0 * nq_pass);
+  if (vec) issue(0);
   int cs_prev = 0, nq_prev = 0;
 #pragma unroll 1
-  for (int pi = 0; pi < npass; pi++) {
-    int pc = pi0 + pi; if (pc >= npass) pc -= npass;
-    int pn = pc + 1; if (pn >= npass) pn -= npass;
-    const int qs = pc * nq_pass;
+  for (int qs = 0; qs < nq_tot; qs += nq_pass) {
     const int cs = 4 * qs;
-    const int nq_cur = nq_pass;
+    const int nq_cur = min(nq_pass, nq_tot - qs);
     if (vec) commit(); else stage_scalar(cs);
     TT_MARK(4);
     if (nq_prev) store_slab(cs_prev, nq_prev);
     TT_MARK(5);
     __syncthreads();
     TT_MARK(6);
-    if (vec && pi + 1 < npass) issue(4 * pn * nq_pass);    // next pass: in flight (registers) while this one is pooled
+    if (vec && qs + nq_pass < nq_tot) issue(cs + 4 * nq_pass);    // next pass: in flight (registers) while this one is pooled
     TT_MARK(7);
     if (it.on) {
       float* so = slab + rl * (4 * nq_cur * bins) + bin;
@@ -338,7 +328,7 @@ __device__ __forceinline__ int tile_work_item(int b, int n, int reverse) {
 }
 
 template <typename TIn, typename TOut, int NT>
-__global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct, int reverse, int phase_t) {
+__global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct, int reverse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileRoi* troi = reinterpret_cast<TileRoi*>(smem);
   TileGroup* tgrp = reinterpret_cast<TileGroup*>(smem + kTileMaxK * kTileRoiBytes);
@@ -356,8 +346,10 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
   int grp = wi / nct;
   int c0 = (wi - grp * nct) * p.ch_block;
   {
-    // reverse bit 2 (development knob DTC_RA_TILE_CBMAJOR): an XCD walks its groups once per CHANNEL BLOCK -- the ~100 workgroups
-    // resident on an XCD then pool the same channel block of ~100 neighbouring groups (with the phase knob: the same channels)
+    // reverse bit 2: an XCD walks its groups once per CHANNEL BLOCK -- the ~100 workgroups resident on an XCD then pool the same
+    // channel block of ~100 neighbouring groups, whose patches overlap 3.6-fold: measured on the bench's box-head launch (round 4,
+    // profiles/r04_a_*) L2 hit rate 0.38 -> 0.51, fabric reads 1.79 -> 1.32 GB, 0.389 -> 0.379 ms.  (Needs the groups to divide
+    // evenly over the XCDs; otherwise the group-major order above.)  A/B: DTC_RA_TILE_CBMAJOR=0.
     const int ngrp = (int)gridDim.x / nct;
     if ((reverse & 4) && ngrp % kXcds == 0 && ngrp >= 2 * kXcds) {
       const int x = blockIdx.x % kXcds, j = blockIdx.x / kXcds, ngx = ngrp / kXcds;
@@ -528,7 +520,7 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
         it.a[iy][ix][0] = t0; it.a[iy][ix][1] = t1; it.a[iy][ix][2] = t2; it.a[iy][ix][3] = t3;
       }
     TT_MARK(2);
-    tile_passes<TIn, TOut, NT>(p, L, fbase, c0, nc, bins, slab, win, troi, g, it, rl, bin, phase_t, tt);
+    tile_passes<TIn, TOut, NT>(p, L, fbase, c0, nc, bins, slab, win, troi, g, it, rl, bin, tt);
   }
 #ifdef DTC_TILE_TRACE
   if (tid == 0 && blockIdx.x < 16384) {
@@ -558,8 +550,7 @@ struct TileConfig {
   int merge_pct = 250; // a cluster may stage at most this % of the pixels its members would stage separately
   int nq_cap = 0;      // channel quads per pass, upper bound (0: 4) -- sizes the LDS output slab
   int reverse = 1;     // walk an XCD's slice of the visiting order back to front (heaviest workgroups first)
-  int cb_major = 0;    // an XCD walks its groups once per channel block (A/B)
-  int phase_t = 0;     // > 0: cyclic pass order from the wall clock, period in units of 10 ns (A/B)
+  int cb_major = 1;    // an XCD walks its groups once per channel block
 };
 static const TileConfig& tile_config() {   // development knobs, resolved ONCE (thread-safe static initialisation)
   static const TileConfig cfg = [] {
@@ -570,7 +561,6 @@ static const TileConfig& tile_config() {   // development knobs, resolved ONCE (
     if (const char* e = getenv("DTC_RA_TILE_NQCAP")) { const int v = atoi(e); if (v >= 1 && v <= 8) c.nq_cap = v; }
     if (const char* e = getenv("DTC_RA_TILE_REVERSE")) c.reverse = atoi(e) != 0;
     if (const char* e = getenv("DTC_RA_TILE_CBMAJOR")) c.cb_major = atoi(e) != 0;
-    if (const char* e = getenv("DTC_RA_TILE_PHASE_T")) { const int v = atoi(e); if (v > 0) c.phase_t = v; }
     if (const char* e = getenv("DTC_RA_TILE_CHBLOCK")) { const int v = atoi(e); if (v >= 4 && (v & 3) == 0) c.ch_block = v; }
     return c;
   }();
@@ -603,7 +593,7 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   while (!cfg.ch_block && cb > 32 && (long long)ngrp * ceil_div(p.channels, cb) < 2048) cb >>= 1;
   p.ch_block = cb;
   const int nct = ceil_div(p.channels, p.ch_block);
-  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, (cfg.reverse ? 1 : 0) | (p.xcd_remap ? 0 : 2) | (cfg.cb_major ? 4 : 0), cfg.phase_t);
+  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, (cfg.reverse ? 1 : 0) | (p.xcd_remap ? 0 : 2) | (cfg.cb_major ? 4 : 0));
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }

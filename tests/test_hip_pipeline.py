@@ -209,3 +209,26 @@ def test_c4_region_path_true_channel_count(oracle, pooled):
                             path.im_w, pooled=pooled)
     assert chain.compare_c4_with_gpu(path, 0, ref)
     assert ref["rois"].shape[0] == 1000
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_channels_last_maps_equal_nchw_maps(oracle, use_graph):
+    """The same inputs with channels_last float32 feature maps (C = 128: two 64-channel items per RoI): box-head features through
+    roi_align_fwd_nhwc_lds, mask-branch features (14 x 14 bins, packed descriptors with padding rows) through the pipelined kernel
+    roi_align_fwd_nhwc_pipe -- every result equal, bit for bit, to the NCHW path's (which the oracle-chain tests pin)."""
+    from detectorch_amd.pipeline import FpnRegionPath, synthetic_batch
+    dev = torch.device("cuda", 0)
+    B, C = 3, 128
+    res = []
+    for cl in (False, True):
+        p = FpnRegionPath(B, dev, channels=C)
+        p.bind(*synthetic_batch(B, dev, seed=3100, channels=C, channels_last=cl))
+        p.crops.zero_()
+        p.step(use_graph=use_graph)
+        if use_graph:
+            p.step(use_graph=True)
+        torch.cuda.synchronize()
+        res.append([t.clone() for t in (p.rois5, p.n_rois, p.box_feats, p.dets, p.det_count, p.mask_feats, p.crops)])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert int(res[0][4].min()) > 0 and float(res[0][5].abs().sum()) > 0

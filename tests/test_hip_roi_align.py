@@ -456,29 +456,41 @@ sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle")); sys.
 import oracle as orc
 from detectorch_amd import hip, synth
 import test_hip_roi_align as T
-for tdt, C in ((torch.float32, 64),) + (((torch.float16, 128), (torch.bfloat16, 256)) if os.environ.get("DTC_RA_NHWC_LDS_16BIT") else ()):
-    feats, rois5, lv = T._nhwc_case(orc, C, 5)
-    tf = [T.cu(f).to(tdt).contiguous(memory_format=torch.channels_last) for f in feats]
-    up = [t.float().contiguous().cpu().numpy() for t in tf]
-    ref = np.zeros((rois5.shape[0], C, 7, 7), np.float32)
-    for l in range(4):
-        m = lv == l
-        if m.any():
-            ref[m] = orc.roi_align_forward(up[l], rois5[m], 7, 7, synth.FPN_ROI_SCALES[l], 2)
-    out = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, T.cu(rois5), 7, 7, 2, roi_levels=T.cu(lv)).cpu().numpy()
-    assert np.array_equal(out, ref), str(tdt)
-    if tdt != torch.float32:
-        o16 = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, T.cu(rois5), 7, 7, 2, roi_levels=T.cu(lv), out_dtype=tdt)
-        assert torch.equal(o16.cpu(), torch.from_numpy(ref).to(tdt))
+sixteen = os.environ.get("DTC_RA_NHWC_LDS_16BIT") or os.environ.get("DTC_RA_NHWC_PIPE16")
+for ph in (7, 14):
+    for tdt, C in ((torch.float32, 64),) + (((torch.float16, 128), (torch.bfloat16, 256)) if sixteen else ()):
+        feats, rois5, lv = T._nhwc_case(orc, C, 5 + ph, R=260 if ph == 7 else 120)
+        tf = [T.cu(f).to(tdt).contiguous(memory_format=torch.channels_last) for f in feats]
+        up = [t.float().contiguous().cpu().numpy() for t in tf]
+        ref = np.zeros((rois5.shape[0], C, ph, ph), np.float32)
+        for l in range(4):
+            m = lv == l
+            if m.any():
+                ref[m] = orc.roi_align_forward(up[l], rois5[m], ph, ph, synth.FPN_ROI_SCALES[l], 2)
+        out = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, T.cu(rois5), ph, ph, 2, roi_levels=T.cu(lv)).cpu().numpy()
+        assert np.array_equal(out, ref), (str(tdt), ph)
+        # visiting order + padding rows through the packed-descriptor entry (the planner's scalar descriptor loads)
+        order = torch.randperm(rois5.shape[0]).to(torch.int32)
+        out2 = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, T.cu(rois5), ph, ph, 2, roi_levels=T.cu(lv), roi_order=order.cuda()).cpu().numpy()
+        assert np.array_equal(out2, ref), ("ordered", str(tdt), ph)
+        if tdt != torch.float32:
+            o16 = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, T.cu(rois5), ph, ph, 2, roi_levels=T.cu(lv), out_dtype=tdt)
+            assert torch.equal(o16.cpu(), torch.from_numpy(ref).to(tdt))
 print("ok")
 """
 
 
 @pytest.mark.parametrize("env", ["DTC_RA_NHWC_LDS_KB=24", "DTC_RA_NHWC_LDS_KB=78", "DTC_RA_NHWC_LDS_KB=156", "DTC_RA_NHWC_LDS=0",
-                                 "DTC_RA_NHWC_LDS_16BIT=1", "DTC_RA_NHWC_LDS_16BIT=1 DTC_RA_NHWC_LDS_KB=24"])
+                                 "DTC_RA_NHWC_LDS_16BIT=1", "DTC_RA_NHWC_LDS_16BIT=1 DTC_RA_NHWC_LDS_KB=24",
+                                 "DTC_RA_NHWC_PIPE=2", "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_LDS_KB=30", "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_LDS_KB=156",
+                                 "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_PIPE16=1", "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_PIPE16=1 DTC_RA_NHWC_LDS_KB=40",
+                                 "DTC_RA_NHWC_PIPE=0"])
 def test_nhwc_lds_image_sizes_in_child_process(hip, oracle, env):
     """The LDS image size decides how many strips a window takes (24 KB: nearly every RoI in several strips or straight from
-    global; 156 KB: one workgroup per CU, one strip) -- and must not change a bit; DTC_RA_NHWC_LDS=0 is the direct-gather kernel."""
+    global; 156 KB: one workgroup per CU, one strip) -- and must not change a bit; DTC_RA_NHWC_LDS=0 is the direct-gather kernel.
+    DTC_RA_NHWC_PIPE=2: the pipelined kernel (round 4) for 7 x 7 bins too (by default it takes the 14 x 14 launches only), at
+    image sizes from a handful of pixels to one workgroup per CU, float32 and 16-bit maps; =0: the round-3 kernels everywhere.
+    Every case: 7 x 7 and 14 x 14 bins, identity and permuted visiting order."""
     import os
     import subprocess
     import sys
