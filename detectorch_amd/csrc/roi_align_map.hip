@@ -271,7 +271,8 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
           // can never sit within 2^-33 (relative) of a rounding boundary of float32 (a 25-bit midpoint times an integer < 2^8
           // is not a 24-bit number), while the double product is within 2^-52 of it -- at 3 instructions instead of the ~12 of
           // an IEEE division (eight of them per RoI and channel group).
-          res[c] = inv_count != 0.f ? res[c] * inv_count : (float)((double)res[c] * rcp_count);
+          // (the argument needs count < 2^8: a very large RoI -- gh * gw >= 256 samples per bin -- takes the IEEE division; uniform branch)
+          res[c] = inv_count != 0.f ? res[c] * inv_count : count < 256.f ? (float)((double)res[c] * rcp_count) : fdiv(res[c], count);
         }
         if (use_slab) {
           // bins <= 64, whole channel quads: [CG][bins] is ONE contiguous run of the output -> wave-private slab, 16-byte stores

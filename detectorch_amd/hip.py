@@ -189,9 +189,10 @@ def bias_act_(x, bias=None, residual=None, relu=True, residual_up2=False):
             raise ValueError("residual must have x's memory layout")
     elif residual_up2:
         raise ValueError("residual_up2 needs a residual")
-    check(lib().dtc_bias_act(x.data_ptr(), bias.data_ptr() if bias is not None else None,
-                             residual.data_ptr() if residual is not None else None, n, c, h, w, _dtype_code(x.dtype), cl,
-                             1 if relu else 0, 1 if residual_up2 else 0, stream_ptr(dev)), "dtc_bias_act")
+    with torch.cuda.device(dev):      # like every other launcher: the kernel goes to x's device whatever the current one is
+        check(lib().dtc_bias_act(x.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                 residual.data_ptr() if residual is not None else None, n, c, h, w, _dtype_code(x.dtype), cl,
+                                 1 if relu else 0, 1 if residual_up2 else 0, stream_ptr(dev)), "dtc_bias_act")
     return x
 
 

@@ -488,6 +488,13 @@ class detector(nn.Module):
         self._paths.clear()
         return self
 
+    def load_state_dict(self, *args, **kw):
+        """Weights are loaded BEFORE optimize_for_inference(): afterwards the conv weights hold the folded BatchNorm scale and the
+        BatchNorm modules are bypassed, so loading into the inference form would silently give a different function."""
+        if getattr(self, "_optimized", False):
+            raise RuntimeError("model is in inference form (optimize_for_inference): load weights into a fresh model, then optimise it")
+        return super().load_state_dict(*args, **kw)
+
     # ---- batched entry: B images, zero host round trips ------------------------------------------------------------------
     def _region_path(self, B, h, w, dev):
         from ..pipeline import FpnRegionPath

@@ -213,7 +213,12 @@ class FpnRegionPath:
         dets = self.dets.cpu().numpy()
         out = []
         for b in range(self.B):
-            n = min(int(cnt[b]), self.max_out)
+            if int(cnt[b]) > self.max_out:
+                # the reference keeps every detection that ties at the image threshold (result_utils.py:159-163); the fixed-shape
+                # rows hold max_out of them: more ties than that must not disappear silently
+                raise RuntimeError("image %d has %d detections (ties at the image threshold) but max_out = %d rows: raise max_out"
+                                   % (b, int(cnt[b]), self.max_out))
+            n = int(cnt[b])
             out.append(dict(boxes=dets[b, :n, :4].copy(), scores=dets[b, :n, 4].copy(), classes=dets[b, :n, 5].astype(np.int32)))
         return out
 

@@ -221,7 +221,9 @@ def assemble_results(dets, det_count, im_sizes=None, rle_str=None, rle_len=None,
         rle_str, rle_len = to_np(rle_str), to_np(rle_len).reshape(N, -1)
         im_sizes = to_np(im_sizes).reshape(N, -1)
     for i in range(N):
-        n = min(int(det_count[i]), max_out)
+        if int(det_count[i]) > max_out:      # ties at the image threshold beyond the fixed rows (result_utils.py:159-163 keeps them all)
+            raise RuntimeError("image %d: %d detections but only %d rows were kept: raise the path's max_out" % (first_image + i, int(det_count[i]), max_out))
+        n = int(det_count[i])
         d = dets[i, :n]
         cls = d[:, 5].astype(np.int64)
         for j in range(1, num_classes):

@@ -52,6 +52,8 @@ def test_bench_self_launch_two_ranks():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * out["config"]["images_per_gpu_per_step"]
+    # the self-verification of the N > 1 line: what rank 0 gathered from rank 1 == rank 1's inputs recomputed on rank 0
+    assert out["consistency"]["gathered_equals_local"] is True and out["consistency"]["gathered_equals_recomputed"] is True
 
 
 def test_bench_refuses_world_size_mismatch():
