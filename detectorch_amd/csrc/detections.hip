@@ -5,7 +5,8 @@
 //   det_candidates   grid (class, image): score > thresh (:127) -> ordered compaction (dets_j order), class-specific box
 //                    decode with weights (10,10,5,5) (lib/utils/boxes.py:168-208) ONLY for the candidates, clip to the
 //                    original image (:150-165), (score desc, index asc) sort in LDS -> NMS input
-//   dtc_nms_sorted   all B x 80 segments in one launch (nms.hip)
+//                    and the segment's hard NMS (cython_nms.pyx:37-87) in the same workgroup: blocks of 64 rows, diagonal tile by
+//                    four waves, greedy walk by one, later columns marked by all (round 4; until then a separate launch pair)
 //   det_finalize     grid (image): max_detections_per_img limit (:154-163) = radix select of the 100-th largest score,
 //                    `>=` filter (ties kept, like the reference), class-major / roi-ascending output (:165).
 #include "block_sort.h"
@@ -29,12 +30,16 @@ struct DetParams {
   int R, n_cls;
   float wx, wy, ww, wh, score_thresh;
   // per (image, class) segment s = b*(n_cls-1) + (j-1), stride R
-  float* sorted_boxes;       // [S, R, 4]   score order (NMS input)
   int32_t* q_of_k;           // [S, R]      sorted rank -> candidate index in dets_j (roi-ascending) order
   float* q_boxes;            // [S, R, 4]   candidate order
   float* q_scores;           // [S, R]
   int32_t* q_roi;            // [S, R]
   int32_t* cand_count;       // [S]
+  // per-class NMS, in this kernel: kept ranks (score order) and their number
+  int32_t* keep;             // [S, R]
+  int32_t* keep_count;       // [S]
+  float nms_thresh;
+  int np2_max;               // next_pow2(R): the sort keys occupy the first np2_max * 8 bytes of the dynamic LDS
 };
 
 // lib/utils/boxes.py:168-208 for one (roi, class)
@@ -122,7 +127,10 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
     __syncthreads();
   }
   const int n = running;
-  if (tid == 0) p.cand_count[seg] = n;
+  if (tid == 0) {
+    p.cand_count[seg] = n;
+    if (n == 0) p.keep_count[seg] = 0;
+  }
   DTC_PT(0, ptb, 1);
   if (n == 0) return;
   const int np2 = next_pow2(n);
@@ -150,21 +158,100 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
   }
   __syncthreads();
   DTC_PT(0, ptb, 3);
-  float4* sb = reinterpret_cast<float4*>(p.sorted_boxes) + (size_t)seg * p.R;
   int32_t* qk = p.q_of_k + (size_t)seg * p.R;
-  for (int k = tid; k < n; k += kDetThreads) {
-    const int q = (int)desc_key_index(keys[k]);
-    qk[k] = q;
-    sb[k] = qb[q];
-  }
+  for (int k = tid; k < n; k += kDetThreads) qk[k] = (int)desc_key_index(keys[k]);
   DTC_PT(0, ptb, 4);
+  // ---- the segment's hard NMS, here (cython_nms.pyx:37-87: greedy over the score order; the kept box of rank i suppresses every
+  // later box j with inter / (area_i + area_j - inter) >= thresh, IEEE division).  The class segments of a detection batch hold tens
+  // of candidates (one 64-row block); as a separate launch pair (mask tiles + reduce over 640 segments) they cost 25 us of which
+  // 20 were launch latency.  Blocks of 64 rows: (1) the four waves form the block's diagonal tile (16 rows each), (2) wave 0 walks
+  // the block greedily with the bits removed by earlier blocks, (3) the block's kept rows mark the later columns they suppress
+  // (one 64-column word per wave and step).  n^2 / 2 pair tests by one workgroup: 50 candidates 3 us, 1000 ~100 us.
+  {
+    float4* sbox = reinterpret_cast<float4*>(smem + (size_t)p.np2_max * sizeof(uint64_t));        // [R] score order
+    uint64_t* removed = reinterpret_cast<uint64_t*>(sbox + p.R);                                    // [(R + 63) / 64]
+    __shared__ uint32_t diag_s[kDetThreads / 64][64];
+    __shared__ uint64_t keptm_s;
+    __shared__ int kept_s;
+    const int ncb = (n + 63) >> 6;
+    for (int k = tid; k < n; k += kDetThreads) sbox[k] = qb[(int)desc_key_index(keys[k])];
+    for (int wd = tid; wd < ncb; wd += kDetThreads) removed[wd] = 0ull;
+    if (tid == 0) kept_s = 0;
+    __syncthreads();
+    const float thr = p.nms_thresh;
+    const bool thr_pos = thr > 0.f;
+    auto area_of = [](const float4& b) { return (b.z - b.x + 1.f) * (b.w - b.y + 1.f); };           // :44
+    // `inter / (area_r + area_c - inter) >= thresh` with an IEEE division -- decided WITHOUT dividing whenever the sign of
+    // d = fl(inter - fl(thresh * u)) is reliable (|d| > 2^-21 thresh u, u > 0, thresh > 0: rounding is monotone, nms.hip explains);
+    // the division only when some lane of the wavefront is inside that band (about one pair in 10^6)
+    auto iou_ge = [&](const float4& r, float rarea, const float4& c, float carea) {
+      const float xx1 = fmaxf(r.x, c.x), yy1 = fmaxf(r.y, c.y), xx2 = fminf(r.z, c.z), yy2 = fminf(r.w, c.w);   // :76-79
+      const float w = fmaxf(0.0f, xx2 - xx1 + 1.f), h = fmaxf(0.0f, yy2 - yy1 + 1.f);                         // :80-81
+      const float inter = w * h;                                                                            // :82
+      const float u = rarea + carea - inter;
+      const float pu = thr * u;
+      const float d = inter - pu;
+      const float t = __builtin_fabsf(d) - pu * 4.76837158203125e-07f;                                       // 2^-21
+      const bool unsure = !(fminf(t, u) > 0.f);
+      if (__builtin_amdgcn_ballot_w64(unsure) == 0ull && thr_pos) return d > 0.f;
+      return (unsure || !thr_pos) ? fdiv(inter, u) >= thr : d > 0.f;                                         // :83-84
+    };
+    int32_t* K = p.keep + (size_t)seg * p.R;
+    const float4 pad = make_float4(0.f, 0.f, -1.f, -1.f);
+    for (int rb = 0; rb < ncb; rb++) {
+      const int i0 = rb * 64, nrow = min(64, n - i0);
+      // (1) diagonal tile: which rows r < lane of this block suppress column i0 + lane; wave wv tests rows [16 wv, 16 wv + 16)
+      const float4 cbx = lane < nrow ? sbox[i0 + lane] : pad;
+      const float carea = area_of(cbx);
+      uint32_t part = 0;
+      for (int r = 16 * wv; r < min(16 * wv + 16, nrow); r++) {
+        const float4 rbx = sbox[i0 + r];                       // uniform address: LDS broadcast
+        const bool sup = lane > r && lane < nrow && iou_ge(rbx, area_of(rbx), cbx, carea);
+        part |= sup ? (1u << (r - 16 * wv)) : 0u;
+      }
+      diag_s[wv][lane] = part;
+      __syncthreads();
+      // (2) greedy walk of the block (wave 0): a row is kept iff no earlier kept row (earlier blocks: `removed`) suppresses it
+      if (wv == 0) {
+        const uint64_t colword = (uint64_t)diag_s[0][lane] | ((uint64_t)diag_s[1][lane] << 16) | ((uint64_t)diag_s[2][lane] << 32) |
+                                 ((uint64_t)diag_s[3][lane] << 48);
+        uint64_t alive = __ballot(lane < nrow) & ~removed[rb];
+        uint64_t keptm = 0ull;
+        for (int r = 0; r < nrow; r++) {
+          if (!((alive >> r) & 1ull)) continue;                // uniform
+          keptm |= 1ull << r;
+          alive &= ~__ballot(((colword >> r) & 1ull) != 0ull);
+        }
+        const int base = kept_s;
+        if ((keptm >> lane) & 1ull) K[base + __builtin_popcountll(keptm & ((1ull << lane) - 1ull))] = i0 + lane;
+        if (lane == 0) { keptm_s = keptm; kept_s = base + __builtin_popcountll(keptm); }
+      }
+      __syncthreads();
+      // (3) the kept rows of this block against every later column: a wave takes one 64-column word per step
+      const uint64_t keptm = keptm_s;
+      for (int c0 = i0 + 64 + 64 * wv; c0 < n; c0 += kDetThreads) {
+        const int j = c0 + lane;
+        const float4 cj = j < n ? sbox[j] : pad;
+        const float aj = area_of(cj);
+        bool sup = false;
+        for (uint64_t km = keptm; km; km &= km - 1ull) {       // uniform
+          const float4 rbx = sbox[i0 + __builtin_ctzll(km)];
+          sup = sup || iou_ge(rbx, area_of(rbx), cj, aj);
+        }
+        const uint64_t m = __ballot(j < n && sup);
+        if (lane == 0 && m) removed[c0 >> 6] |= m;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) p.keep_count[seg] = kept_s;
+  }
 }
 
 constexpr int kFinThreads = 1024;
 constexpr int kFinMaxCls = 256;
 
 struct FinParams {
-  const int32_t* keep;        // [S, R] kept ranks (score order) from dtc_nms_sorted
+  const int32_t* keep;        // [S, R] kept ranks (score order) from det_candidates' NMS
   const int32_t* keep_count;  // [S]
   const int32_t* q_of_k;      // [S, R]
   const float* q_boxes;       // [S, R, 4]
@@ -335,18 +422,12 @@ static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace dtc
 
-extern "C" size_t dtc_nms_sorted_workspace_bytes(int n_seg, int n_stride);
-extern "C" int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg, int n_stride, float thresh,
-                              int max_keep, void* workspace, size_t workspace_bytes, int32_t* keep, int keep_stride,
-                              int32_t* keep_count, dtc_stream_t stream);
-
 namespace dtc {
-struct DetPlan { size_t sorted_boxes, q_of_k, q_boxes, q_scores, q_roi, cand_count, keep, keep_count, sm_stats, nms, total; };
+struct DetPlan { size_t q_of_k, q_boxes, q_scores, q_roi, cand_count, keep, keep_count, sm_stats, total; };
 static DetPlan det_plan(int batch, int R, int n_cls) {
   DetPlan d;
   const size_t S = (size_t)batch * (n_cls - 1);
   size_t o = 0;
-  d.sorted_boxes = o; o += al256(S * R * 4 * sizeof(float));
   d.q_of_k = o; o += al256(S * R * sizeof(int32_t));
   d.q_boxes = o; o += al256(S * R * 4 * sizeof(float));
   d.q_scores = o; o += al256(S * R * sizeof(float));
@@ -355,7 +436,6 @@ static DetPlan det_plan(int batch, int R, int n_cls) {
   d.keep = o; o += al256(S * R * sizeof(int32_t));
   d.keep_count = o; o += al256(S * sizeof(int32_t));
   d.sm_stats = o; o += al256((size_t)batch * R * 2 * sizeof(double));
-  d.nms = o; o += dtc_nms_sorted_workspace_bytes((int)S, R);
   d.total = o;
   return d;
 }
@@ -382,7 +462,6 @@ static int postprocess_detections_impl(const float* rois5, const int32_t* n_rois
   if (workspace_bytes < pl.total) return DTC_EWORKSPACE;
   unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int S = batch * (n_cls - 1);
   dtc::DetParams p;
   p.rois5 = rois5; p.n_rois = n_rois; p.cls_score = cls_score; p.bbox_pred = bbox_pred; p.scale = scaling_factor;
   p.decoded = decoded_boxes;
@@ -397,17 +476,18 @@ static int postprocess_detections_impl(const float* rois5, const int32_t* n_rois
   }
   p.im_size = im_size; p.R = max_rois; p.n_cls = n_cls; p.wx = wx; p.wy = wy; p.ww = ww; p.wh = wh;
   p.score_thresh = score_thresh;
-  p.sorted_boxes = reinterpret_cast<float*>(w + pl.sorted_boxes); p.q_of_k = reinterpret_cast<int32_t*>(w + pl.q_of_k);
+  p.q_of_k = reinterpret_cast<int32_t*>(w + pl.q_of_k);
   p.q_boxes = reinterpret_cast<float*>(w + pl.q_boxes); p.q_scores = reinterpret_cast<float*>(w + pl.q_scores);
   p.q_roi = reinterpret_cast<int32_t*>(w + pl.q_roi); p.cand_count = reinterpret_cast<int32_t*>(w + pl.cand_count);
-  const size_t smem = (size_t)dtc::next_pow2(max_rois) * sizeof(uint64_t);
-  hipLaunchKernelGGL(dtc::det_candidates_kernel, dim3(n_cls - 1, batch), dim3(dtc::kDetThreads), smem, s, p);
-  DTC_CHECK_LAUNCH();
+  // dynamic LDS: sort keys [next_pow2(R)] x 8 B, then the segment's boxes in score order [R] x 16 B and one removed-bit per box
+  const int np2 = dtc::next_pow2(max_rois);
+  const size_t smem = (size_t)np2 * sizeof(uint64_t) + (size_t)max_rois * sizeof(float4) + (size_t)((max_rois + 63) / 64) * sizeof(uint64_t);
+  if (smem > 48 * 1024) { DTC_RAISE_LDS_ONCE(dtc::det_candidates_kernel, 152 * 1024); }
   int32_t* keep = reinterpret_cast<int32_t*>(w + pl.keep);
   int32_t* keep_count = reinterpret_cast<int32_t*>(w + pl.keep_count);
-  int rc = dtc_nms_sorted(p.sorted_boxes, p.cand_count, S, max_rois, nms_thresh, 0, w + pl.nms,
-                          dtc_nms_sorted_workspace_bytes(S, max_rois), keep, max_rois, keep_count, stream);
-  if (rc != DTC_OK) return rc;
+  p.keep = keep; p.keep_count = keep_count; p.nms_thresh = nms_thresh; p.np2_max = np2;
+  hipLaunchKernelGGL(dtc::det_candidates_kernel, dim3(n_cls - 1, batch), dim3(dtc::kDetThreads), smem, s, p);
+  DTC_CHECK_LAUNCH();
   dtc::FinParams f;
   f.keep = keep; f.keep_count = keep_count; f.q_of_k = p.q_of_k; f.q_boxes = p.q_boxes; f.q_scores = p.q_scores;
   f.q_roi = p.q_roi; f.scale = scaling_factor; f.R = max_rois; f.n_cls = n_cls; f.max_det = max_det; f.max_out = max_out;

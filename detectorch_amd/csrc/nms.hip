@@ -225,6 +225,7 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const uint64_t* __restri
                                                         int keep_stride, int32_t* __restrict__ keep_count) {
   __shared__ uint64_t removed[256];            // one bit per box, up to 16384 boxes
   const int s = blockIdx.x, lane = threadIdx.x, rg = lane >> 4, cbl = lane & 15;
+  if (counts && counts[s] < 0) return;         // a segment somebody else has already reduced (det_candidates: <= 64 candidates)
   const int n = counts ? min(counts[s], n_stride) : n_stride;
   const int ncb = (n + 63) >> 6;
   const uint64_t* M = mask + (size_t)s * n_stride * ncb_stride;
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(kReduceLdsThreads) void nms_reduce_lds_kernel(const
       if (pr >= ppr) { pr -= ppr; row++; }
     }
     n = counts ? min(counts[s], n_stride) : n_stride;
+    if (n < 0) return;                           // a segment somebody else has already reduced (uniform: the whole workgroup leaves)
     row = row0; pr = pr0;
 #pragma unroll
     for (int k = 0; k < kPerThread; k++) {

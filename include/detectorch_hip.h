@@ -108,7 +108,8 @@ int dtc_nms(const float* dets, int n, float thresh, void* workspace, size_t work
 /* Segmented NMS over score-SORTED boxes: one launch for all (image, level) / (image, class) segments -- replaces the
  * per-level loop of lib/model/detector.py:252 + generate_proposals.py:115-117 and the 80-iteration loop of
  * lib/utils/result_utils.py:126-143.  boxes float32 [n_seg, n_stride, 4] sorted by score descending inside each
- * segment; counts int32 [n_seg] (NULL: all n_stride valid).  keep int32 [n_seg, keep_stride] receives the kept
+ * segment; counts int32 [n_seg] (NULL: all n_stride valid; a NEGATIVE count marks a segment that is already reduced: its
+ * keep / keep_count are left untouched).  keep int32 [n_seg, keep_stride] receives the kept
  * POSITIONS in score order, at most max_keep (>0) of them (== keep[:post_nms_top_n]); keep_count int32 [n_seg]. */
 size_t dtc_nms_sorted_workspace_bytes(int n_seg, int n_stride);
 int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg, int n_stride, float thresh, int max_keep,

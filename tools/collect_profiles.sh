@@ -45,7 +45,7 @@ wl = "cfg3"
 toks = os.environ.get("BENCH_ARGS", "").split()
 for tok in toks:
     if tok in ("cfg2", "cfg3", "cfg5"): wl = tok
-nhwc, f16 = "--channels-last" in toks, ("--fp16" in toks or wl == "cfg5")
+nhwc, f16 = ("--channels-last" in toks or (wl == "cfg5" and "--nchw" not in toks)), ("--fp16" in toks or wl == "cfg5")
 if res:
     g = max(res, key=lambda k: int(k))
     key = "%s_b8_%s_%s" % (wl, "nhwc" if nhwc else "nchw", "f16" if f16 else "f32")
