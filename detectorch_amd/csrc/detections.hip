@@ -30,13 +30,13 @@ struct DetParams {
   int R, n_cls;
   float wx, wy, ww, wh, score_thresh;
   // per (image, class) segment s = b*(n_cls-1) + (j-1), stride R
-  int32_t* q_of_k;           // [S, R]      sorted rank -> candidate index in dets_j (roi-ascending) order
   float* q_boxes;            // [S, R, 4]   candidate order
   float* q_scores;           // [S, R]
   int32_t* q_roi;            // [S, R]
   int32_t* cand_count;       // [S]
-  // per-class NMS, in this kernel: kept ranks (score order) and their number
-  int32_t* keep;             // [S, R]
+  // per-class NMS, in this kernel: the sort keys (~ordered score << 32 | candidate index q) of the kept boxes, in score order,
+  // and their number -- everything det_finalize needs about a kept box in ONE load
+  uint64_t* kept_key;        // [S, R]
   int32_t* keep_count;       // [S]
   float nms_thresh;
   int np2_max;               // next_pow2(R): the sort keys occupy the first np2_max * 8 bytes of the dynamic LDS
@@ -99,32 +99,43 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
   DTC_PT(0, ptb, 0);
   if (tid == 0) running = 0;
   __syncthreads();
-  // ordered compaction of {r : scores[r, j] > thresh}  (np.where, result_utils.py:127)
-  for (int r0 = 0; r0 < nr; r0 += kDetThreads) {
-    const int r = r0 + tid;
-    float s = 0.f;
-    bool ok = false;
-    if (r < nr) {
-      s = sc[(size_t)r * p.n_cls];
-      if (p.sm_stats) {      // logits in: softmax column formed here (detector.py:281)
-        const double* st = p.sm_stats + ((size_t)b * p.R + r) * 2;
-        s = (float)(exp((double)s - st[0]) / st[1]);
+  // ordered compaction of {r : scores[r, j] > thresh}  (np.where, result_utils.py:127).  The scores of FOUR chunks of 256 rois are
+  // requested before the first is consumed (one global round trip per 1024 rois instead of one per 256: 5.7 -> ~3 us at 1000 rois)
+  for (int R0 = 0; R0 < nr; R0 += 4 * kDetThreads) {
+    float sv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = R0 + u * kDetThreads + tid;
+      sv[u] = 0.f;
+      if (r < nr) {
+        sv[u] = sc[(size_t)r * p.n_cls];
+        if (p.sm_stats) {      // logits in: softmax column formed here (detector.py:281)
+          const double* st = p.sm_stats + ((size_t)b * p.R + r) * 2;
+          sv[u] = (float)(exp((double)sv[u] - st[0]) / st[1]);
+        }
       }
-      ok = s > p.score_thresh;
     }
-    const uint64_t m = __ballot(ok);
-    if (lane == 0) wave_tot[wv] = __builtin_popcountll(m);
-    __syncthreads();
-    int base = running;
-    for (int q = 0; q < wv; q++) base += wave_tot[q];
-    if (ok) {
-      const int q = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-      qroi[q] = r; qs[q] = s;
-      keys[q] = make_desc_key(s, (uint32_t)q);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r0 = R0 + u * kDetThreads;
+      if (r0 >= nr) break;                                     // uniform
+      const int r = r0 + tid;
+      const float s = sv[u];
+      const bool ok = r < nr && s > p.score_thresh;
+      const uint64_t m = __ballot(ok);
+      if (lane == 0) wave_tot[wv] = __builtin_popcountll(m);
+      __syncthreads();
+      int base = running;
+      for (int q = 0; q < wv; q++) base += wave_tot[q];
+      if (ok) {
+        const int q = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        qroi[q] = r; qs[q] = s;
+        keys[q] = make_desc_key(s, (uint32_t)q);
+      }
+      __syncthreads();
+      if (tid == 0) { int t = 0; for (int q = 0; q < kDetThreads / 64; q++) t += wave_tot[q]; running += t; }
+      __syncthreads();
     }
-    __syncthreads();
-    if (tid == 0) { int t = 0; for (int q = 0; q < kDetThreads / 64; q++) t += wave_tot[q]; running += t; }
-    __syncthreads();
   }
   const int n = running;
   if (tid == 0) {
@@ -139,10 +150,15 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
   DTC_PT(0, ptb, 2);
   // decode candidate q (once), then emit both the candidate-order and the score-order copies
   float4* qb = reinterpret_cast<float4*>(p.q_boxes) + (size_t)seg * p.R;
+  float4* sbox = reinterpret_cast<float4*>(smem + (size_t)p.np2_max * sizeof(uint64_t));        // [R] the boxes again, for the NMS below
+  uint32_t* rank_of_q = reinterpret_cast<uint32_t*>(sbox + p.R);                                 // [R] score rank of candidate q
+  for (int k = tid; k < n; k += kDetThreads) rank_of_q[desc_key_index(keys[k])] = (uint32_t)k;
+  __syncthreads();
   if (p.decoded) {          // lib/utils/result_utils.py:128: boxes[inds, j * 4:(j + 1) * 4] taken as they are
     for (int q = tid; q < n; q += kDetThreads) {
       const float* d = p.decoded + ((size_t)b * p.R + qroi[q]) * 4 * p.n_cls + 4 * j;
-      qb[q] = make_float4(d[0], d[1], d[2], d[3]);
+      const float4 v = make_float4(d[0], d[1], d[2], d[3]);
+      qb[q] = v; sbox[rank_of_q[q]] = v;
     }
   }
   const float sf = p.decoded ? 1.f : p.scale[b];
@@ -154,12 +170,11 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
     const float rr[4] = {roi[0], roi[1], roi[2], roi[3]};
     float o[4];
     decode_det(rr, sf, d, p.wx, p.wy, p.ww, p.wh, im_h, im_w, o);
-    qb[q] = make_float4(o[0], o[1], o[2], o[3]);
+    const float4 v = make_float4(o[0], o[1], o[2], o[3]);
+    qb[q] = v; sbox[rank_of_q[q]] = v;                     // candidate order (global, det_finalize) and score order (LDS, the NMS)
   }
   __syncthreads();
   DTC_PT(0, ptb, 3);
-  int32_t* qk = p.q_of_k + (size_t)seg * p.R;
-  for (int k = tid; k < n; k += kDetThreads) qk[k] = (int)desc_key_index(keys[k]);
   DTC_PT(0, ptb, 4);
   // ---- the segment's hard NMS, here (cython_nms.pyx:37-87: greedy over the score order; the kept box of rank i suppresses every
   // later box j with inter / (area_i + area_j - inter) >= thresh, IEEE division).  The class segments of a detection batch hold tens
@@ -168,13 +183,12 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
   // the block greedily with the bits removed by earlier blocks, (3) the block's kept rows mark the later columns they suppress
   // (one 64-column word per wave and step).  n^2 / 2 pair tests by one workgroup: 50 candidates 3 us, 1000 ~100 us.
   {
-    float4* sbox = reinterpret_cast<float4*>(smem + (size_t)p.np2_max * sizeof(uint64_t));        // [R] score order
-    uint64_t* removed = reinterpret_cast<uint64_t*>(sbox + p.R);                                    // [(R + 63) / 64]
+    uint64_t* removed = reinterpret_cast<uint64_t*>(rank_of_q + ((p.R + 1) & ~1));                  // [(R + 63) / 64]
     __shared__ uint32_t diag_s[kDetThreads / 64][64];
     __shared__ uint64_t keptm_s;
     __shared__ int kept_s;
     const int ncb = (n + 63) >> 6;
-    for (int k = tid; k < n; k += kDetThreads) sbox[k] = qb[(int)desc_key_index(keys[k])];
+    DTC_PT(0, ptb, 5);
     for (int wd = tid; wd < ncb; wd += kDetThreads) removed[wd] = 0ull;
     if (tid == 0) kept_s = 0;
     __syncthreads();
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
       if (__builtin_amdgcn_ballot_w64(unsure) == 0ull && thr_pos) return d > 0.f;
       return (unsure || !thr_pos) ? fdiv(inter, u) >= thr : d > 0.f;                                         // :83-84
     };
-    int32_t* K = p.keep + (size_t)seg * p.R;
+    uint64_t* K = p.kept_key + (size_t)seg * p.R;
     const float4 pad = make_float4(0.f, 0.f, -1.f, -1.f);
     for (int rb = 0; rb < ncb; rb++) {
       const int i0 = rb * 64, nrow = min(64, n - i0);
@@ -211,39 +225,58 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
       }
       diag_s[wv][lane] = part;
       __syncthreads();
+      DTC_PT(0, ptb, 6 + 3 * min(rb, 2));
       // (2) greedy walk of the block (wave 0): a row is kept iff no earlier kept row (earlier blocks: `removed`) suppresses it
       if (wv == 0) {
         const uint64_t colword = (uint64_t)diag_s[0][lane] | ((uint64_t)diag_s[1][lane] << 16) | ((uint64_t)diag_s[2][lane] << 32) |
                                  ((uint64_t)diag_s[3][lane] << 48);
-        uint64_t alive = __ballot(lane < nrow) & ~removed[rb];
-        uint64_t keptm = 0ull;
-        for (int r = 0; r < nrow; r++) {
-          if (!((alive >> r) & 1ull)) continue;                // uniform
-          keptm |= 1ull << r;
-          alive &= ~__ballot(((colword >> r) & 1ull) != 0ull);
+        // the greedy answer as a fixed point: row j is kept iff it is a candidate and no KEPT earlier row of the block suppresses it;
+        // K <- {j : cand_j and colword_j & K == 0} from K = cand settles rows in increasing order (row 0 after one step, row j once
+        // the rows before it have settled) -- a few wave-wide steps instead of one dependent step per row
+        const uint64_t cand = __ballot(lane < nrow) & ~removed[rb];
+        const bool mine = (cand >> lane) & 1ull;
+        uint64_t keptm = cand;
+        for (int it = 0; it < 64; it++) {
+          const uint64_t nk = __ballot(mine && (colword & keptm) == 0ull);
+          if (nk == keptm) break;
+          keptm = nk;
         }
         const int base = kept_s;
-        if ((keptm >> lane) & 1ull) K[base + __builtin_popcountll(keptm & ((1ull << lane) - 1ull))] = i0 + lane;
+        if ((keptm >> lane) & 1ull) K[base + __builtin_popcountll(keptm & ((1ull << lane) - 1ull))] = keys[i0 + lane];
         if (lane == 0) { keptm_s = keptm; kept_s = base + __builtin_popcountll(keptm); }
       }
       __syncthreads();
+      DTC_PT(0, ptb, 7 + 3 * min(rb, 2));
       // (3) the kept rows of this block against every later column: a wave takes one 64-column word per step
       const uint64_t keptm = keptm_s;
+      const int nkept = __builtin_popcountll(keptm);
+      const bool row_kept = (keptm >> lane) & 1ull;          // lane <-> row i0 + lane of this block (cbx / carea from step 1)
       for (int c0 = i0 + 64 + 64 * wv; c0 < n; c0 += kDetThreads) {
-        const int j = c0 + lane;
-        const float4 cj = j < n ? sbox[j] : pad;
-        const float aj = area_of(cj);
-        bool sup = false;
-        for (uint64_t km = keptm; km; km &= km - 1ull) {       // uniform
-          const float4 rbx = sbox[i0 + __builtin_ctzll(km)];
-          sup = sup || iou_ge(rbx, area_of(rbx), cj, aj);
+        const int ncol = min(64, n - c0);
+        uint64_t m = 0ull;
+        if (nkept <= ncol) {                                  // lane <-> column, loop over the kept rows
+          const int j = c0 + lane;
+          const float4 cj = j < n ? sbox[j] : pad;
+          const float aj = area_of(cj);
+          bool sup = false;
+          for (uint64_t km = keptm; km; km &= km - 1ull) {     // uniform
+            const float4 rbx = sbox[i0 + __builtin_ctzll(km)];
+            sup = sup || iou_ge(rbx, area_of(rbx), cj, aj);
+          }
+          m = __ballot(j < n && sup);
+        } else {                                              // few columns (a segment's tail): lane <-> kept row, loop over the columns
+          for (int c = 0; c < ncol; c++) {
+            const float4 cj = sbox[c0 + c];                     // broadcast
+            const bool sup = row_kept && iou_ge(cbx, carea, cj, area_of(cj));
+            if (__ballot(sup) != 0ull) m |= 1ull << c;
+          }
         }
-        const uint64_t m = __ballot(j < n && sup);
         if (lane == 0 && m) removed[c0 >> 6] |= m;
       }
       __syncthreads();
     }
     if (tid == 0) p.keep_count[seg] = kept_s;
+    DTC_PT(0, ptb, 15);
   }
 }
 
@@ -251,9 +284,8 @@ constexpr int kFinThreads = 1024;
 constexpr int kFinMaxCls = 256;
 
 struct FinParams {
-  const int32_t* keep;        // [S, R] kept ranks (score order) from det_candidates' NMS
+  const uint64_t* kept_key;   // [S, R] sort keys of the kept boxes (det_candidates' NMS): ~ordered score << 32 | candidate index q
   const int32_t* keep_count;  // [S]
-  const int32_t* q_of_k;      // [S, R]
   const float* q_boxes;       // [S, R, 4]
   const float* q_scores;      // [S, R]
   const int32_t* q_roi;       // [S, R]
@@ -302,11 +334,11 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
   const bool staged = total <= kFinStage;
   // kept entry f of this image -> (ordered score, candidate index q, class c)
   auto fetch = [&](int c, int e, uint32_t& o, int& q) {
-    const int seg = seg0 + c;
-    q = p.q_of_k[(size_t)seg * p.R + p.keep[(size_t)seg * p.R + e]];
-    o = float_to_ordered(p.q_scores[(size_t)seg * p.R + q]);
+    const uint64_t key = p.kept_key[(size_t)(seg0 + c) * p.R + e];
+    q = (int)desc_key_index(key);
+    o = ~(uint32_t)(key >> 32);                             // == float_to_ordered(q_scores[q]) (block_sort.h: make_desc_key)
   };
-  if (staged) {   // three dependent global loads per entry, paid once, in parallel; every later phase runs from LDS
+  if (staged) {   // one global load per entry, paid once, in parallel; every later phase runs from LDS
     for (int f = tid; f < total; f += kFinThreads) {
       int lo = 0, hi = nseg;
       while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (koff[mid] <= f) lo = mid; else hi = mid; }
@@ -423,17 +455,16 @@ static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 }  // namespace dtc
 
 namespace dtc {
-struct DetPlan { size_t q_of_k, q_boxes, q_scores, q_roi, cand_count, keep, keep_count, sm_stats, total; };
+struct DetPlan { size_t q_boxes, q_scores, q_roi, cand_count, kept_key, keep_count, sm_stats, total; };
 static DetPlan det_plan(int batch, int R, int n_cls) {
   DetPlan d;
   const size_t S = (size_t)batch * (n_cls - 1);
   size_t o = 0;
-  d.q_of_k = o; o += al256(S * R * sizeof(int32_t));
   d.q_boxes = o; o += al256(S * R * 4 * sizeof(float));
   d.q_scores = o; o += al256(S * R * sizeof(float));
   d.q_roi = o; o += al256(S * R * sizeof(int32_t));
   d.cand_count = o; o += al256(S * sizeof(int32_t));
-  d.keep = o; o += al256(S * R * sizeof(int32_t));
+  d.kept_key = o; o += al256(S * R * sizeof(uint64_t));
   d.keep_count = o; o += al256(S * sizeof(int32_t));
   d.sm_stats = o; o += al256((size_t)batch * R * 2 * sizeof(double));
   d.total = o;
@@ -476,20 +507,21 @@ static int postprocess_detections_impl(const float* rois5, const int32_t* n_rois
   }
   p.im_size = im_size; p.R = max_rois; p.n_cls = n_cls; p.wx = wx; p.wy = wy; p.ww = ww; p.wh = wh;
   p.score_thresh = score_thresh;
-  p.q_of_k = reinterpret_cast<int32_t*>(w + pl.q_of_k);
   p.q_boxes = reinterpret_cast<float*>(w + pl.q_boxes); p.q_scores = reinterpret_cast<float*>(w + pl.q_scores);
   p.q_roi = reinterpret_cast<int32_t*>(w + pl.q_roi); p.cand_count = reinterpret_cast<int32_t*>(w + pl.cand_count);
-  // dynamic LDS: sort keys [next_pow2(R)] x 8 B, then the segment's boxes in score order [R] x 16 B and one removed-bit per box
+  // dynamic LDS: sort keys [next_pow2(R)] x 8 B, then the segment's boxes in score order [R] x 16 B, the rank of every candidate
+  // [R] x 4 B and one removed-bit per box
   const int np2 = dtc::next_pow2(max_rois);
-  const size_t smem = (size_t)np2 * sizeof(uint64_t) + (size_t)max_rois * sizeof(float4) + (size_t)((max_rois + 63) / 64) * sizeof(uint64_t);
+  const size_t smem = (size_t)np2 * sizeof(uint64_t) + (size_t)max_rois * sizeof(float4) + (size_t)((max_rois + 1) & ~1) * sizeof(uint32_t) +
+                      (size_t)((max_rois + 63) / 64) * sizeof(uint64_t);
   if (smem > 48 * 1024) { DTC_RAISE_LDS_ONCE(dtc::det_candidates_kernel, 152 * 1024); }
-  int32_t* keep = reinterpret_cast<int32_t*>(w + pl.keep);
+  uint64_t* kept_key = reinterpret_cast<uint64_t*>(w + pl.kept_key);
   int32_t* keep_count = reinterpret_cast<int32_t*>(w + pl.keep_count);
-  p.keep = keep; p.keep_count = keep_count; p.nms_thresh = nms_thresh; p.np2_max = np2;
+  p.kept_key = kept_key; p.keep_count = keep_count; p.nms_thresh = nms_thresh; p.np2_max = np2;
   hipLaunchKernelGGL(dtc::det_candidates_kernel, dim3(n_cls - 1, batch), dim3(dtc::kDetThreads), smem, s, p);
   DTC_CHECK_LAUNCH();
   dtc::FinParams f;
-  f.keep = keep; f.keep_count = keep_count; f.q_of_k = p.q_of_k; f.q_boxes = p.q_boxes; f.q_scores = p.q_scores;
+  f.kept_key = kept_key; f.keep_count = keep_count; f.q_boxes = p.q_boxes; f.q_scores = p.q_scores;
   f.q_roi = p.q_roi; f.scale = scaling_factor; f.R = max_rois; f.n_cls = n_cls; f.max_det = max_det; f.max_out = max_out;
   f.dets = dets; f.det_roi = det_roi; f.det_rois_scaled = det_rois_scaled; f.det_count = det_count;
   hipLaunchKernelGGL(dtc::det_finalize_kernel, dim3(batch), dim3(dtc::kFinThreads), 0, s, f);
