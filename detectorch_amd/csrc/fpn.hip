@@ -485,8 +485,7 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
   p.roi_levels = roi_levels; p.n_out = n_out; p.rois_by_level = rois_by_level; p.level_counts = level_counts;
   // visiting-order band height (log2 feature rows): 16 rows suits the cluster-stationary RoIAlign kernel (clusters of ~5
   // neighbours stay ~28 rows x 32 pixels; measured 8 rows 0.48, 16 rows 0.41, 32 rows 0.43 ms per 8000-RoI box-head launch)
-  static const int band_log2 = [] { const char* e = getenv("DTC_FPN_BAND_LOG2"); const int v = e ? atoi(e) : 4; return v < 0 || v > 8 ? 4 : v; }();
-  p.band_log2 = band_log2;
+  p.band_log2 = 4;
   p.idx_restore = idx_restore; p.roi_order = roi_order; p.roi_desc = roi_order ? roi_desc : nullptr;
   size_t smem = in_scores ? (size_t)dtc::next_pow2((int)n_max) * sizeof(uint64_t) : 16;
   if (in_scores && inputs_sorted) smem = (size_t)post_nms_top_n * sizeof(uint64_t) + (size_t)n_max * sizeof(float) + 16;

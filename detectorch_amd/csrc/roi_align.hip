@@ -727,11 +727,10 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
 //   DTC_ROIALIGN_MAP=0           single-level inputs (C4) through the RoI-stationary kernel instead of the map-stationary one (roi_align_map.hip)
 //   DTC_ROIALIGN_GENERAL=1       force the per-output gather kernel (the plain statement of the arithmetic)
 //   DTC_ROIALIGN_NO_NHWC_DIRECT  channels_last features through the LDS-staged kernel
-//   DTC_ROIALIGN_LDS_KB (52)  DTC_RA_CHBLOCK (128 / 64)  DTC_RA_NO_XCD  DTC_RA_NO_CTS64
+//   DTC_RA_NO_XCD  DTC_RA_NO_CTS64
 struct RoiAlignConfig {
   bool tile = true, map = true, general = false, nhwc_direct = true, xcd = true, cts64 = true;
-  int ch_block = 0, lds_bytes = 52 * 1024;
-  int nhwc_wide16 = 1;        // DTC_RA_NHWC_WIDE16=0: 16-bit channels_last maps with > 64 bins go back to the LDS kernel (A/B)
+  int lds_bytes = 52 * 1024;
 };
 static const RoiAlignConfig& roi_align_config() {
   static const RoiAlignConfig cfg = [] {
@@ -742,9 +741,6 @@ static const RoiAlignConfig& roi_align_config() {
     c.nhwc_direct = getenv("DTC_ROIALIGN_NO_NHWC_DIRECT") == nullptr;
     c.xcd = getenv("DTC_RA_NO_XCD") == nullptr;
     c.cts64 = getenv("DTC_RA_NO_CTS64") == nullptr;      // 64-channel sub-tiles for windows <= 128 px: +4 % on the bench workload
-    if (const char* e = getenv("DTC_RA_NHWC_WIDE16")) c.nhwc_wide16 = atoi(e) != 0;
-    if (const char* e = getenv("DTC_RA_CHBLOCK")) { const int v = atoi(e); if (v >= 64 && v % 64 == 0) c.ch_block = v; }
-    if (const char* e = getenv("DTC_ROIALIGN_LDS_KB")) { const int v = atoi(e); if (v >= 16 && v <= 160) c.lds_bytes = v * 1024; }
     return c;
   }();
   return cfg;
@@ -844,7 +840,6 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   // Measured on MI355X, 8000 RoIs x 256 ch: 64 -> 0.710 ms, 128 -> 0.704 ms, 256 -> 0.760 ms.
   p.ch_block = channels > 64 ? 128 : 64;
   if ((long long)n_rois * ((channels + p.ch_block - 1) / p.ch_block) < 3072) p.ch_block = 64;
-  if (cfg.ch_block) p.ch_block = cfg.ch_block;
   p.xcd_remap = cfg.xcd; p.cts64 = cfg.cts64;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // LDS-staged kernel for every pooled size whose output slab fits; adaptive sampling (sampling_ratio <= 0) included
@@ -861,7 +856,7 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   if (all_nhwc && !cfg.general && cfg.nhwc_direct && dtc::roi_align_nhwc_lds_supported(p, in_dtype, out_dtype))
     return dtc::launch_roi_align_nhwc_lds(p, in_dtype, out_dtype, s);
   // 16-bit channels_last maps, 2 x 2 samples: the direct kernel's 8-channel lanes (16-byte tap loads) for every bin count
-  const bool wide16 = in_dtype != DTC_F32 && sampling_ratio == 2 && channels % 32 == 0 && cfg.nhwc_wide16;
+  const bool wide16 = in_dtype != DTC_F32 && sampling_ratio == 2 && channels % 32 == 0;
   if (lds_ok && all_nhwc && (few_taps || wide16) && cfg.nhwc_direct) return dtc::launch_typed(dtc::kKernNhwc, p, in_dtype, out_dtype, s);
   // one level whose whole map fits LDS (the C4 heads), adaptive sampling: the map-stationary kernel (roi_align_map.hip)
   if (cfg.map && !cfg.general && sampling_ratio != 2 && dtc::roi_align_map_supported(p, in_dtype, out_dtype))

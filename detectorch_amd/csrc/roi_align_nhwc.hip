@@ -678,8 +678,8 @@ namespace dtc {
 //                           1024-RoI launch against 0.180 for the RoI-stationary LDS kernel (roi_align.hip) that took these before.
 // Float32 output only for the pipelined kernel.  Development / A-B knobs, resolved once per process: DTC_RA_NHWC_LDS=0 (neither
 // kernel), DTC_RA_NHWC_LDS_KB, DTC_RA_NHWC_PIPE = 0 never / 1 by bin count (default) / 2 always, DTC_RA_NHWC_PIPE16=1 /
-// DTC_RA_NHWC_LDS_16BIT=1 (16-bit maps too), DTC_RA_NHWC_WGS.
-struct NlConfig { int enabled = 1, lds_kb = 0, pipe = 1, pipe16 = 0, wgs = 0; };
+// DTC_RA_NHWC_LDS_16BIT=1 (16-bit maps too).
+struct NlConfig { int enabled = 1, lds_kb = 0, pipe = 1, pipe16 = 0; };
 static const NlConfig& nl_config() {
   static const NlConfig cfg = [] {
     NlConfig c;
@@ -687,7 +687,6 @@ static const NlConfig& nl_config() {
     if (const char* e = getenv("DTC_RA_NHWC_LDS_KB")) { const int v = atoi(e); if (v >= 24 && v <= 160) c.lds_kb = v; }
     if (const char* e = getenv("DTC_RA_NHWC_PIPE")) { const int v = atoi(e); if (v >= 0 && v <= 2) c.pipe = v; }
     if (const char* e = getenv("DTC_RA_NHWC_PIPE16")) c.pipe16 = atoi(e) != 0;
-    if (const char* e = getenv("DTC_RA_NHWC_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 8) c.wgs = v; }
     return c;
   }();
   return cfg;
@@ -704,7 +703,7 @@ static bool np_plan(int in_dtype, NpPlan& pl) {
   const int room = pl.lds_b - kNpHdrBytes - kNpPoolWaves * cb * kNpScrPitch * 4;
   pl.img_pixels = room < 0 ? 0 : ((room / 2 / kNlChunk) & ~3);       // two images; the DMA writes whole groups of 4 pixels
   if (pl.img_pixels > 8188) pl.img_pixels = 8188;                     // pixel indices stay exact in the float reciprocal
-  pl.wgs_per_cu = cfg.wgs ? cfg.wgs : (160 * 1024) / pl.lds_b;
+  pl.wgs_per_cu = (160 * 1024) / pl.lds_b;
   if (pl.wgs_per_cu > 4) pl.wgs_per_cu = 4;                           // 512 threads each, 2048 per CU
   if (pl.wgs_per_cu < 1) pl.wgs_per_cu = 1;
   return pl.img_pixels >= 16;

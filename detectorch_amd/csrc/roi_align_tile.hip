@@ -552,14 +552,9 @@ struct TileConfig {
   int reverse = 1;     // walk an XCD's slice of the visiting order back to front (heaviest workgroups first)
   int cb_major = 1;    // an XCD walks its groups once per channel block
 };
-static const TileConfig& tile_config() {   // development knobs, resolved ONCE (thread-safe static initialisation)
+static const TileConfig& tile_config() {   // A/B knobs (DTC_RA_TILE_CHBLOCK, DTC_RA_TILE_CBMAJOR), resolved ONCE (thread-safe static initialisation)
   static const TileConfig cfg = [] {
     TileConfig c;
-    if (const char* e = getenv("DTC_RA_TILE_LDS_KB")) { const int v = atoi(e); if (v >= 8 && v <= 160) c.lds_kb = v; }
-    if (const char* e = getenv("DTC_RA_TILE_K")) { const int v = atoi(e); if (v >= 1 && v <= kTileMaxK) c.k = v; }
-    if (const char* e = getenv("DTC_RA_TILE_MERGE")) { const int v = atoi(e); if (v >= 100 && v <= 100000) c.merge_pct = v; }
-    if (const char* e = getenv("DTC_RA_TILE_NQCAP")) { const int v = atoi(e); if (v >= 1 && v <= 8) c.nq_cap = v; }
-    if (const char* e = getenv("DTC_RA_TILE_REVERSE")) c.reverse = atoi(e) != 0;
     if (const char* e = getenv("DTC_RA_TILE_CBMAJOR")) c.cb_major = atoi(e) != 0;
     if (const char* e = getenv("DTC_RA_TILE_CHBLOCK")) { const int v = atoi(e); if (v >= 4 && (v & 3) == 0) c.ch_block = v; }
     return c;

@@ -278,7 +278,10 @@ int dtc_box_voting(const float* top_dets, int n_top, const float* all_dets, int 
                    float* top_dets_out, int32_t* n_voters, dtc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * A10  Convolution epilogue of the inference model (the call sites that carry the path, lib/model/detector.py)
+ * OUTSIDE SURVEY section 8 (the region-proposal hot path): convolution epilogue of the backbone's inference form.
+ * SURVEY 2 row 7 marks the backbone out of scope; this entry exists because detector.optimize_for_inference (round 3)
+ * uses it.  It is frozen: no parity / roofline claim of this library rests on it, and a binding of the hot path does
+ * not need it.
  * --------------------------------------------------------------------------------------------------------------- */
 
 /* x [n,c,h,w] (dense NCHW, or dense channels_last when channels_last != 0; DTC_F32 / DTC_F16 / DTC_BF16), in place:
