@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--channels-last", action="store_true", help="NHWC feature maps (same logical shape); the default for cfg5")
     ap.add_argument("--nchw", action="store_true", help="cfg5 only: NCHW fp16 feature maps instead of channels_last")
     ap.add_argument("--fp16", action="store_true", help="fp16 feature maps / pooled features (cfg5 sets this itself)")
+    ap.add_argument("--max-out", type=int, default=104, help="fixed detection rows per image through the mask branch: max_detections_per_img = 100 plus room for ties at the image threshold (the reference keeps them, result_utils.py:159-163; more ties than rows raise); 128 until round 3")
     ap.add_argument("--c4-pooled", type=int, default=7, help="cfg2: pooled size (7 as BASELINE names it; 14 = the reference's C4 default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-always", action="store_true", help="run the per-step RCCL all-gather of the detections even at world size 1 (tests: exercises the N > 1 code path on one GPU; needs a launcher environment)")
@@ -270,12 +271,12 @@ def main():
             p = C4RegionPath(a.batch, dev, pooled=a.c4_pooled, feat_dtype=fdt)
             inp = synthetic_c4_batch(a.batch, dev, seed=seed, feat_dtype=fdt)
         else:
-            kw = dict(feat_dtype=fdt, collect_top_n=top_n)
+            kw = dict(feat_dtype=fdt, collect_top_n=top_n, max_out=a.max_out)
             if a.split > 1 and a.batch % a.split == 0:
                 p = OverlappedRegionPath(a.batch, dev, n_split=a.split, **kw)
             else:
                 p = FpnRegionPath(a.batch, dev, **kw)
-            inp = synthetic_batch(a.batch, dev, seed=seed, top_n=top_n, feat_dtype=fdt, channels_last=a.channels_last)
+            inp = synthetic_batch(a.batch, dev, seed=seed, top_n=top_n, feat_dtype=fdt, channels_last=a.channels_last, max_out=a.max_out)
         p.bind(*inp)
         paths.append(p)
         inputs.append(inp)
@@ -365,6 +366,31 @@ def main():
     k_ms = float(np.mean(k_all))
     alg_bytes = paths[0].box_roialign_bytes()
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    fast_mode = None
+    if wl == "cfg2":                          # the same launch in the kernel's FAST mode (dtc_roi_align_set_exact(0): merged taps, not bit-identical)
+        exact_feats = paths[0].box_feats.clone()
+        hip.roi_align_set_exact(False)
+        try:
+            for _ in range(3):
+                paths[0]._roi_align_box()
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record()
+            for _ in range(iters):
+                paths[i % NSETS]._roi_align_box()
+            f1.record()
+            torch.cuda.synchronize(dev)
+            f_ms = f0.elapsed_time(f1) / iters
+            paths[0]._roi_align_box()
+            torch.cuda.synchronize(dev)
+            fast_mode = {"launch_ms": round(f_ms, 4), "frac": round(alg_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "max_abs_diff_vs_exact": float((paths[0].box_feats.float() - exact_feats.float()).abs().max()),
+                         "what": "dtc_roi_align_set_exact(0): (gh+1)x(gw+1) merged taps with separable weight sums instead of gh x gw x 4; "
+                                 "the timed steps and the parity check above ran in exact mode"}
+        finally:
+            hip.roi_align_set_exact(True)
+            for pth in paths:                 # leave exact results behind
+                pth._roi_align_box()
+            torch.cuda.synchronize(dev)
     harder = None
     if wl != "cfg2":                          # the same launch on the harder RoI population (a trained RPN looks like it)
         h_ms = harder_set_launch(paths[0], inputs[0][2], top_n, dev, max(5, iters // 2))
@@ -397,7 +423,7 @@ def main():
         for r in range(1, world):
             seed_r = base + 500 * s_last + r
             inp_r = (synthetic_c4_batch(a.batch, dev, seed=seed_r, feat_dtype=fdt) if wl == "cfg2" else
-                     synthetic_batch(a.batch, dev, seed=seed_r, top_n=top_n, feat_dtype=fdt, channels_last=a.channels_last))
+                     synthetic_batch(a.batch, dev, seed=seed_r, top_n=top_n, feat_dtype=fdt, channels_last=a.channels_last, max_out=a.max_out))
             pv.bind(*inp_r)
             pv.step(use_graph=False)         # eager: the captured graph holds the pointers of the original input set
             torch.cuda.synchronize(dev)
@@ -459,6 +485,7 @@ def main():
             "vs_baseline": None, "dtype": "f16" if fp16 else "f32", "data": "synthetic",
             "config": {"workload": desc, "workload_id": wl,
                        "images_per_gpu_per_step": a.batch, "global_batch": a.batch * world, "rois_per_image": top_n,
+                       "detection_rows_per_image": None if wl == "cfg2" else a.max_out,
                        "input_sets_rotated": NSETS,
                        "feature_layout": "NHWC" if a.channels_last else "NCHW",
                        "launch": ("eager" if a.eager else "hipGraph") + (", %d sub-batches on %d streams" % (a.split, a.split) if isinstance(p0, OverlappedRegionPath) else "") +
@@ -488,6 +515,7 @@ def main():
                                                                       "images_per_sec": round(a.batch * n_sus * world / dt_sus, 2)}},
         }
         out["roofline"]["harder_set"] = harder
+        out["roofline"]["fast_mode"] = fast_mode
         if not a.no_cpu_baseline and not isinstance(p0, OverlappedRegionPath):
             p0.step(use_graph=not a.eager)          # the configuration that was timed, on input set 0
             torch.cuda.synchronize(dev)

@@ -884,6 +884,9 @@ DTC_API int dtc_roi_align_forward_packed(const dtc_feat_level* levels, int n_lev
 
 DTC_API size_t dtc_roi_align_workspace_bytes(int n_rois) { return dtc::roi_align_map_workspace_bytes(n_rois); }
 
+DTC_API void dtc_roi_align_set_exact(int exact) { dtc::roi_align_set_exact(exact); }
+DTC_API int dtc_roi_align_get_exact(void) { return dtc::roi_align_get_exact(); }
+
 DTC_API int dtc_roi_align_forward_packed_ws(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,
                                             const float* roi_desc, int n_rois, int pooled_h, int pooled_w, int sampling_ratio,
                                             void* out, int out_dtype, void* workspace, size_t workspace_bytes, dtc_stream_t stream) {

@@ -119,6 +119,8 @@ int launch_roi_align_tile(const RoiAlignParams& p, int in_dtype, int out_dtype, 
 // launchers of the map-stationary kernel (roi_align_map.hip): single-level inputs whose whole map fits LDS
 bool roi_align_map_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
 int launch_roi_align_map(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream);
+void roi_align_set_exact(int exact);                   // 0: the map-stationary kernel may merge taps (<= 1e-5 from exact); default 1
+int roi_align_get_exact();
 size_t roi_align_map_workspace_bytes(int n_rois);      // per-launch preparation records (optional: workspace == nullptr -> none)
 int launch_roi_align_map_ws(const RoiAlignParams& p, int in_dtype, int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream);
 

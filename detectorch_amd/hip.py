@@ -57,6 +57,10 @@ def lib():
     L.launch_roi_align_forward_hip.restype = i
     L.dtc_roi_align_forward.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, p, i, i, i, i, p, i, p]
     L.dtc_roi_align_forward.restype = i
+    L.dtc_roi_align_set_exact.argtypes = [i]
+    L.dtc_roi_align_set_exact.restype = None
+    L.dtc_roi_align_get_exact.argtypes = []
+    L.dtc_roi_align_get_exact.restype = i
     L.dtc_roi_align_forward_ordered.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, p, p, i, i, i, i, p, i, p]
     L.dtc_roi_align_forward_ordered.restype = i
     sz = C.c_size_t
@@ -194,6 +198,12 @@ def bias_act_(x, bias=None, residual=None, relu=True, residual_up2=False):
                                  residual.data_ptr() if residual is not None else None, n, c, h, w, _dtype_code(x.dtype), cl,
                                  1 if relu else 0, 1 if residual_up2 else 0, stream_ptr(dev)), "dtc_bias_act")
     return x
+
+
+def roi_align_set_exact(exact=True):
+    """Process-wide switch (dtc_roi_align_set_exact): True (default) = bit-identical to the reference; False = the C4 (adaptive
+    sampling, single level) kernel may merge taps -- the same sums in exact arithmetic, <= 1e-5 from the reference in float32."""
+    lib().dtc_roi_align_set_exact(1 if exact else 0)
 
 
 def roi_align_forward(features, spatial_scales, rois, pooled_h, pooled_w, sampling_ratio, roi_levels=None,

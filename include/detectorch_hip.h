@@ -89,6 +89,14 @@ int dtc_roi_align_forward_packed(const dtc_feat_level* levels, int n_levels, int
  * preparation kernel instead of once per (RoI, 8-channel workgroup).  Same results bit for bit; configurations that do not
  * take that kernel ignore the workspace (NULL is allowed: then this IS dtc_roi_align_forward_packed). */
 size_t dtc_roi_align_workspace_bytes(int n_rois);
+
+/* Exactness switch of the adaptive-sampling (sampling_ratio <= 0) single-level path, process-wide, read at launch time.
+ * exact = 1 (default): the reference's float32 operations in the reference's order (roi_align_cpu_loop.cpp:203-216): bit-identical.
+ * exact = 0: with a workspace (dtc_roi_align_forward_packed_ws) the kernel may merge the gh x gw samples x 4 taps of a bin into
+ * (gh + 1) x (gw + 1) taps with separable weight sums: the same sum in exact arithmetic, <= 1e-5 away in float32 on O(1) features
+ * (BASELINE.json's tolerance for pooled features is 1e-4), about a quarter faster on the C4 heads. */
+void dtc_roi_align_set_exact(int exact);
+int dtc_roi_align_get_exact(void);
 int dtc_roi_align_forward_packed_ws(const dtc_feat_level* levels, int n_levels, int channels, int in_dtype,
                                     const float* roi_desc, int n_rois, int pooled_h, int pooled_w, int sampling_ratio, void* out,
                                     int out_dtype, void* workspace, size_t workspace_bytes, dtc_stream_t stream);

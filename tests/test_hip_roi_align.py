@@ -243,6 +243,25 @@ def test_map_stationary_kernel_vs_oracle(hip, oracle, case):
     rc = hip.lib().dtc_roi_align_forward_packed_ws(lvs, 1, ch, hip._dtype_code(dt), cu(desc).data_ptr(), n + 5, ph, pw, sr,
                                                    out2.data_ptr(), 0, ws.data_ptr(), ws.numel(), hip.stream_ptr())
     assert rc == 0 and torch.equal(out2, out)
+    # fast mode (dtc_roi_align_set_exact(0)): merged taps with separable weight sums -- the same sums in exact arithmetic, within
+    # 1e-5 of the bit-exact result in float32 (BASELINE.json allows 1e-4 on pooled features); padding rows still zero; and the
+    # switch back restores bit-identity
+    try:
+        hip.roi_align_set_exact(False)
+        out3 = torch.full((n + 5, C, ph, pw), 7.0, device="cuda")
+        rc = hip.lib().dtc_roi_align_forward_packed_ws(lvs, 1, ch, hip._dtype_code(dt), cu(desc).data_ptr(), n + 5, ph, pw, sr,
+                                                       out3.data_ptr(), 0, ws.data_ptr(), ws.numel(), hip.stream_ptr())
+        assert rc == 0
+        d = (out3 - out).abs().max().item()
+        assert d <= 1e-5 * max(1.0, float(out.abs().max())), d
+        if sr == 0 and case not in ("fp16",):
+            assert not torch.equal(out3, out)          # the fast path really ran (a different association moves some last bits)
+    finally:
+        hip.roi_align_set_exact(True)
+    out4 = torch.full((n + 5, C, ph, pw), 9.0, device="cuda")
+    rc = hip.lib().dtc_roi_align_forward_packed_ws(lvs, 1, ch, hip._dtype_code(dt), cu(desc).data_ptr(), n + 5, ph, pw, sr,
+                                                   out4.data_ptr(), 0, ws.data_ptr(), ws.numel(), hip.stream_ptr())
+    assert rc == 0 and torch.equal(out4, out)
 
 
 _VARIANT_CHILD = r"""
