@@ -375,8 +375,8 @@ def main():
                 paths[0]._roi_align_box()
             f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             f0.record()
-            for _ in range(iters):
-                paths[i % NSETS]._roi_align_box()
+            for it_ in range(iters):
+                paths[it_ % NSETS]._roi_align_box()
             f1.record()
             torch.cuda.synchronize(dev)
             f_ms = f0.elapsed_time(f1) / iters
