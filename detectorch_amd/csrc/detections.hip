@@ -17,6 +17,7 @@ namespace dtc {
 DTC_PT_TABLE(detections)
 
 constexpr int kDetThreads = 256;
+constexpr int kNmsLdsCap = 512;       // candidates of a (class, image) segment whose boxes the in-workgroup NMS keeps in LDS
 
 struct DetParams {
   const float* rois5;        // [B, R, 5]
@@ -30,6 +31,7 @@ struct DetParams {
   int R, n_cls;
   float wx, wy, ww, wh, score_thresh;
   // per (image, class) segment s = b*(n_cls-1) + (j-1), stride R
+  float* sorted_boxes;       // [S, R, 4]   score order: scratch of the NMS for segments of more than kNmsLdsCap candidates
   float* q_boxes;            // [S, R, 4]   candidate order
   float* q_scores;           // [S, R]
   int32_t* q_roi;            // [S, R]
@@ -150,15 +152,19 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
   DTC_PT(0, ptb, 2);
   // decode candidate q (once), then emit both the candidate-order and the score-order copies
   float4* qb = reinterpret_cast<float4*>(p.q_boxes) + (size_t)seg * p.R;
-  float4* sbox = reinterpret_cast<float4*>(smem + (size_t)p.np2_max * sizeof(uint64_t));        // [R] the boxes again, for the NMS below
-  uint32_t* rank_of_q = reinterpret_cast<uint32_t*>(sbox + p.R);                                 // [R] score rank of candidate q
-  for (int k = tid; k < n; k += kDetThreads) rank_of_q[desc_key_index(keys[k])] = (uint32_t)k;
+  // the boxes again in SCORE order for the NMS below: in LDS when the segment has at most kNmsLdsCap candidates (the usual tens to
+  // a few hundred), else in the global scratch p.sorted_boxes -- LDS sized for every possible segment would leave 2 workgroups per CU
+  float4* sbox_l = reinterpret_cast<float4*>(smem + (size_t)p.np2_max * sizeof(uint64_t));     // [kNmsLdsCap]
+  uint32_t* rank_of_q = reinterpret_cast<uint32_t*>(sbox_l + kNmsLdsCap);                        // [kNmsLdsCap] score rank of candidate q
+  const bool in_lds = n <= kNmsLdsCap;
+  if (in_lds) for (int k = tid; k < n; k += kDetThreads) rank_of_q[desc_key_index(keys[k])] = (uint32_t)k;
   __syncthreads();
   if (p.decoded) {          // lib/utils/result_utils.py:128: boxes[inds, j * 4:(j + 1) * 4] taken as they are
     for (int q = tid; q < n; q += kDetThreads) {
       const float* d = p.decoded + ((size_t)b * p.R + qroi[q]) * 4 * p.n_cls + 4 * j;
       const float4 v = make_float4(d[0], d[1], d[2], d[3]);
-      qb[q] = v; sbox[rank_of_q[q]] = v;
+      qb[q] = v;
+      if (in_lds) sbox_l[rank_of_q[q]] = v;
     }
   }
   const float sf = p.decoded ? 1.f : p.scale[b];
@@ -171,7 +177,8 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
     float o[4];
     decode_det(rr, sf, d, p.wx, p.wy, p.ww, p.wh, im_h, im_w, o);
     const float4 v = make_float4(o[0], o[1], o[2], o[3]);
-    qb[q] = v; sbox[rank_of_q[q]] = v;                     // candidate order (global, det_finalize) and score order (LDS, the NMS)
+    qb[q] = v;                                             // candidate order (global, det_finalize)
+    if (in_lds) sbox_l[rank_of_q[q]] = v;                  // score order (LDS, the NMS)
   }
   __syncthreads();
   DTC_PT(0, ptb, 3);
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
   // the block greedily with the bits removed by earlier blocks, (3) the block's kept rows mark the later columns they suppress
   // (one 64-column word per wave and step).  n^2 / 2 pair tests by one workgroup: 50 candidates 3 us, 1000 ~100 us.
   {
-    uint64_t* removed = reinterpret_cast<uint64_t*>(rank_of_q + ((p.R + 1) & ~1));                  // [(R + 63) / 64]
+    uint64_t* removed = reinterpret_cast<uint64_t*>(rank_of_q + kNmsLdsCap);                         // [(R + 63) / 64]
     __shared__ uint32_t diag_s[kDetThreads / 64][64];
     __shared__ uint64_t keptm_s;
     __shared__ int kept_s;
@@ -212,6 +219,13 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
     };
     uint64_t* K = p.kept_key + (size_t)seg * p.R;
     const float4 pad = make_float4(0.f, 0.f, -1.f, -1.f);
+    float4* sorted_g = reinterpret_cast<float4*>(p.sorted_boxes) + (size_t)seg * p.R;
+    if (!in_lds) {          // a large segment: its boxes in score order through the global scratch
+      for (int k = tid; k < n; k += kDetThreads) sorted_g[k] = qb[(int)desc_key_index(keys[k])];
+      __syncthreads();
+    }
+    auto run_blocks = [&](auto lds_tag) {
+    const float4* sbox = decltype(lds_tag)::value ? static_cast<const float4*>(sbox_l) : static_cast<const float4*>(sorted_g);
     for (int rb = 0; rb < ncb; rb++) {
       const int i0 = rb * 64, nrow = min(64, n - i0);
       // (1) diagonal tile: which rows r < lane of this block suppress column i0 + lane; wave wv tests rows [16 wv, 16 wv + 16)
@@ -249,32 +263,27 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
       DTC_PT(0, ptb, 7 + 3 * min(rb, 2));
       // (3) the kept rows of this block against every later column: a wave takes one 64-column word per step
       const uint64_t keptm = keptm_s;
-      const int nkept = __builtin_popcountll(keptm);
-      const bool row_kept = (keptm >> lane) & 1ull;          // lane <-> row i0 + lane of this block (cbx / carea from step 1)
-      for (int c0 = i0 + 64 + 64 * wv; c0 < n; c0 += kDetThreads) {
-        const int ncol = min(64, n - c0);
-        uint64_t m = 0ull;
-        if (nkept <= ncol) {                                  // lane <-> column, loop over the kept rows
+      // wave wv takes the block's rows [16 wv, 16 wv + 16) against EVERY later 64-column word (lane <-> column): a segment of ~100
+      // candidates has one such word, and its ~50 kept rows are four waves' 13 instead of one wave's 50
+      const uint64_t mine_rows = keptm & (0xffffull << (16 * wv));
+      if (mine_rows) {
+        for (int c0 = i0 + 64; c0 < n; c0 += 64) {
           const int j = c0 + lane;
           const float4 cj = j < n ? sbox[j] : pad;
           const float aj = area_of(cj);
           bool sup = false;
-          for (uint64_t km = keptm; km; km &= km - 1ull) {     // uniform
+          for (uint64_t km = mine_rows; km; km &= km - 1ull) {   // uniform
             const float4 rbx = sbox[i0 + __builtin_ctzll(km)];
             sup = sup || iou_ge(rbx, area_of(rbx), cj, aj);
           }
-          m = __ballot(j < n && sup);
-        } else {                                              // few columns (a segment's tail): lane <-> kept row, loop over the columns
-          for (int c = 0; c < ncol; c++) {
-            const float4 cj = sbox[c0 + c];                     // broadcast
-            const bool sup = row_kept && iou_ge(cbx, carea, cj, area_of(cj));
-            if (__ballot(sup) != 0ull) m |= 1ull << c;
-          }
+          const uint64_t m = __ballot(j < n && sup);
+          if (lane == 0 && m) atomicOr(reinterpret_cast<unsigned long long*>(&removed[c0 >> 6]), (unsigned long long)m);
         }
-        if (lane == 0 && m) removed[c0 >> 6] |= m;
       }
       __syncthreads();
     }
+    };
+    if (in_lds) run_blocks(std::true_type{}); else run_blocks(std::false_type{});
     if (tid == 0) p.keep_count[seg] = kept_s;
     DTC_PT(0, ptb, 15);
   }
@@ -311,17 +320,20 @@ template <typename F> __device__ __forceinline__ void fin_prefix(int* off, F cnt
   if (lane == 63 && nseg >= 256) off[nseg] = e;
 }
 
-constexpr int kFinStage = 6144;   // kept entries staged in LDS (ordered score + class/candidate id); more -> global path
+// kept entries staged in LDS (ordered score + candidate id, 8 bytes each): dynamic, sized by the launcher for the worst case the
+// arguments allow up to kFinStageMax (128 KB); more -> every pass re-fetches from global
+constexpr int kFinStageMax = 16384;
 
-__global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) {
+__global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p, int stage_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
+  uint32_t* st_key = reinterpret_cast<uint32_t*>(fin_smem);             // [stage_cap] ordered score of kept entry f
+  uint32_t* st_cq = st_key + stage_cap;                                   // [stage_cap] candidate index q of kept entry f
   __shared__ __attribute__((aligned(16))) uint32_t h[2048];
   __shared__ uint32_t sh[2];
   __shared__ int koff[kFinMaxCls + 1];
   __shared__ int ccnt[kFinMaxCls];
   __shared__ int coff[kFinMaxCls + 1];
   __shared__ uint64_t bitmap[kFinThreads / 64][64];  // per wave: up to 4096 candidates per class
-  __shared__ uint32_t st_key[kFinStage];             // ordered score of kept entry f
-  __shared__ uint32_t st_cq[kFinStage];              // candidate index q of kept entry f
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nseg = p.n_cls - 1;
   const int seg0 = b * nseg;
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p) 
   if (wv == 0) fin_prefix(koff, [&](int c) { return c < nseg ? p.keep_count[seg0 + c] : 0; }, nseg, lane);
   __syncthreads();
   const int total = koff[nseg];
-  const bool staged = total <= kFinStage;
+  const bool staged = total <= stage_cap;
   // kept entry f of this image -> (ordered score, candidate index q, class c)
   auto fetch = [&](int c, int e, uint32_t& o, int& q) {
     const uint64_t key = p.kept_key[(size_t)(seg0 + c) * p.R + e];
@@ -455,11 +467,12 @@ static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 }  // namespace dtc
 
 namespace dtc {
-struct DetPlan { size_t q_boxes, q_scores, q_roi, cand_count, kept_key, keep_count, sm_stats, total; };
+struct DetPlan { size_t sorted_boxes, q_boxes, q_scores, q_roi, cand_count, kept_key, keep_count, sm_stats, total; };
 static DetPlan det_plan(int batch, int R, int n_cls) {
   DetPlan d;
   const size_t S = (size_t)batch * (n_cls - 1);
   size_t o = 0;
+  d.sorted_boxes = o; o += al256(S * R * 4 * sizeof(float));
   d.q_boxes = o; o += al256(S * R * 4 * sizeof(float));
   d.q_scores = o; o += al256(S * R * sizeof(float));
   d.q_roi = o; o += al256(S * R * sizeof(int32_t));
@@ -507,12 +520,13 @@ static int postprocess_detections_impl(const float* rois5, const int32_t* n_rois
   }
   p.im_size = im_size; p.R = max_rois; p.n_cls = n_cls; p.wx = wx; p.wy = wy; p.ww = ww; p.wh = wh;
   p.score_thresh = score_thresh;
+  p.sorted_boxes = reinterpret_cast<float*>(w + pl.sorted_boxes);
   p.q_boxes = reinterpret_cast<float*>(w + pl.q_boxes); p.q_scores = reinterpret_cast<float*>(w + pl.q_scores);
   p.q_roi = reinterpret_cast<int32_t*>(w + pl.q_roi); p.cand_count = reinterpret_cast<int32_t*>(w + pl.cand_count);
-  // dynamic LDS: sort keys [next_pow2(R)] x 8 B, then the segment's boxes in score order [R] x 16 B, the rank of every candidate
-  // [R] x 4 B and one removed-bit per box
+  // dynamic LDS: sort keys [next_pow2(R)] x 8 B, then up to kNmsLdsCap boxes in score order (16 B) + their ranks (4 B) and one
+  // removed-bit per candidate
   const int np2 = dtc::next_pow2(max_rois);
-  const size_t smem = (size_t)np2 * sizeof(uint64_t) + (size_t)max_rois * sizeof(float4) + (size_t)((max_rois + 1) & ~1) * sizeof(uint32_t) +
+  const size_t smem = (size_t)np2 * sizeof(uint64_t) + (size_t)dtc::kNmsLdsCap * (sizeof(float4) + sizeof(uint32_t)) +
                       (size_t)((max_rois + 63) / 64) * sizeof(uint64_t);
   if (smem > 48 * 1024) { DTC_RAISE_LDS_ONCE(dtc::det_candidates_kernel, 152 * 1024); }
   uint64_t* kept_key = reinterpret_cast<uint64_t*>(w + pl.kept_key);
@@ -524,7 +538,12 @@ static int postprocess_detections_impl(const float* rois5, const int32_t* n_rois
   f.kept_key = kept_key; f.keep_count = keep_count; f.q_boxes = p.q_boxes; f.q_scores = p.q_scores;
   f.q_roi = p.q_roi; f.scale = scaling_factor; f.R = max_rois; f.n_cls = n_cls; f.max_det = max_det; f.max_out = max_out;
   f.dets = dets; f.det_roi = det_roi; f.det_rois_scaled = det_rois_scaled; f.det_count = det_count;
-  hipLaunchKernelGGL(dtc::det_finalize_kernel, dim3(batch), dim3(dtc::kFinThreads), 0, s, f);
+  long long cap = (long long)max_rois * (n_cls - 1);            // every candidate of every class kept
+  if (cap > dtc::kFinStageMax) cap = dtc::kFinStageMax;
+  const int stage_cap = (int)((cap + 3) & ~3ll);
+  const size_t fsm = (size_t)stage_cap * 8;
+  if (fsm > 32 * 1024) { DTC_RAISE_LDS_ONCE(dtc::det_finalize_kernel, 132 * 1024); }      // + ~18 KB static
+  hipLaunchKernelGGL(dtc::det_finalize_kernel, dim3(batch), dim3(dtc::kFinThreads), fsm, s, f, stage_cap);
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }

@@ -200,6 +200,36 @@ def test_postprocess_batched_vs_oracle(hip, oracle, R, max_det):
         assert np.array_equal(scaled[b, :c].cpu().numpy(), rd[:c, :4] * sf[b])
 
 
+@pytest.mark.parametrize("R,n_cls", [(1500, 3), (700, 2), (130, 5)])
+def test_postprocess_crowded_classes_vs_oracle(hip, oracle, R, n_cls):
+    """Few classes, so every class segment holds hundreds to ~1500 candidates with heavy overlap: the in-workgroup NMS of
+    det_candidates runs many 64-row blocks, every later-column word, and -- above 512 candidates -- takes the boxes from the global
+    scratch instead of LDS; 130 candidates = 3 blocks with a short tail.  Small clustered boxes, so that most are suppressed."""
+    B = 2
+    rs = synth.rng(5, R + n_cls)
+    base = np.stack([synth.make_rois(rs, R, min_side=60.0, max_side=260.0) for _ in range(B)])
+    base[:, :, :2] = base[:, :, :2] * 0.25 + 300.0                       # crowd the boxes into a quarter of the image
+    base[:, :, 2:] = base[:, :, :2] + (base[:, :, 2:] - base[:, :, :2]) * 0.25 + 40.0
+    rois5 = np.concatenate([np.zeros((B, R, 1), np.float32), base], 2).astype(np.float32)
+    logits = rs.standard_normal((B, R, n_cls)).astype(np.float32)
+    e = np.exp(logits - logits.max(2, keepdims=True))
+    cls = (e / e.sum(2, keepdims=True)).astype(np.float32)
+    cls += (np.arange(R, dtype=np.float32)[None, :, None] * 1e-7)          # tie-free
+    dl = (rs.standard_normal((B, R, 4 * n_cls)) * 0.05).astype(np.float32)
+    n_rois = np.array([R, R - 11], np.int32)
+    sf = np.array([1.6, 1.0], np.float32)
+    im = np.array([[500, 833], [800, 1333]], np.float32)
+    cap = 4096
+    dets, roi, scaled, cnt = hip.postprocess_detections(cu(rois5), cu(n_rois), cu(cls), cu(dl), cu(sf), cu(im), max_det=0, max_out=cap)
+    for b in range(B):
+        n = n_rois[b]
+        rd, rr = oracle.postprocess_detections(base[b, :n].astype(np.float32), sf[b], im[b], cls[b, :n], dl[b, :n], max_det=0)
+        c = int(cnt[b])
+        assert c == rd.shape[0] and 0 < c < n * (n_cls - 1)              # something kept, something suppressed
+        assert np.array_equal(dets[b, :c].cpu().numpy(), rd[:c])
+        assert np.array_equal(roi[b, :c].cpu().numpy(), rr[:c])
+
+
 # ---------------------------------------------------------------- A9 ------------------------------------------------
 @pytest.mark.parametrize("M", [14, 28])
 def test_mask_geometry_golden(hip, M):
