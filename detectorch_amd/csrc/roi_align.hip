@@ -551,6 +551,23 @@ template <> __device__ __forceinline__ float hi16_to_f32<bf16_t>(uint32_t w) { r
 template <> __device__ __forceinline__ float lo16_to_f32<float>(uint32_t w) { return 0.f; }      // never instantiated for float maps
 template <> __device__ __forceinline__ float hi16_to_f32<float>(uint32_t w) { return 0.f; }
 
+// {w * float(low half), w * float(high half)} of a dword of two 16-bit elements, as a register pair for the packed fp32 adds.
+// fp16: v_fma_mix_f32 converts and multiplies in ONE instruction -- fma(float(x), w, -0.0) is round(float(x) * w), the value
+// v_cvt_f32_f16 + v_mul_f32 give (adding -0 never changes a sum).  bf16: two bit operations, one v_pk_mul_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ f32x2 mul_pair16(uint32_t u, float w);
+template <> __device__ __forceinline__ f32x2 mul_pair16<__half>(uint32_t u, float w) {
+  f32x2 r;
+  asm("v_fma_mix_f32 %0, %2, %3, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, %3, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(r.x), "=&v"(r.y) : "v"(u), "v"(w), "s"(-0.0f));
+  return r;
+}
+template <> __device__ __forceinline__ f32x2 mul_pair16<bf16_t>(uint32_t u, float w) {
+  const f32x2 v = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+  return v * w;
+}
+template <> __device__ __forceinline__ f32x2 mul_pair16<float>(uint32_t, float) { return f32x2{0.f, 0.f}; }   // never instantiated for float maps
+
 // [n_out] float32 slab -> contiguous output of type TOut: 16-byte stores where the alignment allows (4 floats, or 8 16-bit values
 // rounded exactly as from_f32 does element by element); a 2-byte store per element cost 12 x the time per byte
 template <typename TOut, int THREADS>
@@ -621,29 +638,40 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
     // a 7 x 7 RoI takes TWO rounds of 16 loads in flight per lane where the 4-channel mapping below takes four -- the kernel is
     // bound by those dependent L1 / L2 round trips, not by bytes (0.32 -> 0.2x ms per 8000-RoI launch).  Same arithmetic, same order.
     const bool wide = nc == CB && tab_ok && gh == 2 && gw == 2 && ((L.stride_h | L.stride_w | L.stride_n) & 7) == 0 &&
-                      (reinterpret_cast<uintptr_t>(L.data) & 15) == 0 && inv_count != 0.f;
+                      (reinterpret_cast<uintptr_t>(L.data) & 15) == 0 && inv_count != 0.f &&
+                      (int64_t)L.stride_h * L.height + (int64_t)L.stride_w * L.width < (1ll << 30);     // 32-bit byte offsets
     if (wide) {
       constexpr int NQ8 = CB / 8;
       const int q8 = tid % NQ8, slot8 = tid / NQ8;
-      const TIn* base8 = reinterpret_cast<const TIn*>(L.data) + (int64_t)b * L.stride_n + c0 + 8 * q8;
-      auto ld = [&](int yo, int xo) { return *reinterpret_cast<const uint4*>(base8 + yo + xo); };
-      auto taps = [&](int bin, uint4* t, AxisEntry* ax) {          // ax: y0 y1 x0 x1 of the bin
-        const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
+      // one scalar base for the workgroup, 32-bit byte offsets per lane (global_load ... saddr): a tap costs one v_add
+      const int bu = __builtin_amdgcn_readfirstlane(b);
+      const char* ubase = reinterpret_cast<const char*>(reinterpret_cast<const TIn*>(L.data) + (int64_t)bu * L.stride_n + c0);
+      const uint32_t lane_off = 16u * (uint32_t)q8;
+      auto ld = [&](uint32_t yo, uint32_t xo) { return *reinterpret_cast<const uint4*>(ubase + (yo + xo)); };
+      // bin -> (ph, pw) without a division per round: the lane's bins are slot8, slot8 + 32, ...
+      constexpr int kStep = kRoiAlignThreads / NQ8;
+      const int step_h = kStep / p.pooled_w, step_w = kStep - step_h * p.pooled_w;
+      int ph = slot8 / p.pooled_w, pw = slot8 - ph * p.pooled_w;
+      for (int bin = slot8; bin < bins; bin += kStep) {
         const AxisEntry y0e = ytab[ph * 2], y1e = ytab[ph * 2 + 1], x0e = xtab[pw * 2], x1e = xtab[pw * 2 + 1];
-        ax[0] = y0e; ax[1] = y1e; ax[2] = x0e; ax[3] = x1e;
-        t[0] = ld(y0e.lo, x0e.lo); t[1] = ld(y0e.lo, x0e.hi); t[2] = ld(y0e.hi, x0e.lo); t[3] = ld(y0e.hi, x0e.hi);
-        t[4] = ld(y0e.lo, x1e.lo); t[5] = ld(y0e.lo, x1e.hi); t[6] = ld(y0e.hi, x1e.lo); t[7] = ld(y0e.hi, x1e.hi);
-        t[8] = ld(y1e.lo, x0e.lo); t[9] = ld(y1e.lo, x0e.hi); t[10] = ld(y1e.hi, x0e.lo); t[11] = ld(y1e.hi, x0e.hi);
-        t[12] = ld(y1e.lo, x1e.lo); t[13] = ld(y1e.lo, x1e.hi); t[14] = ld(y1e.hi, x1e.lo); t[15] = ld(y1e.hi, x1e.hi);
-      };
-      auto pool = [&](int bin, const uint4* t, const AxisEntry* ax) {
-        float a[8];
+        // byte offsets (tables hold element offsets inside the image; the map is < 2^31 bytes per image -- checked by `wide`)
+        const uint32_t ya = 2u * (uint32_t)y0e.lo + lane_off, yb = 2u * (uint32_t)y0e.hi + lane_off;
+        const uint32_t yc = 2u * (uint32_t)y1e.lo + lane_off, yd = 2u * (uint32_t)y1e.hi + lane_off;
+        const uint32_t xa = 2u * (uint32_t)x0e.lo, xb = 2u * (uint32_t)x0e.hi, xc = 2u * (uint32_t)x1e.lo, xd = 2u * (uint32_t)x1e.hi;
+        uint4 t[16];        // all 16 taps in flight before the first one is consumed
+        t[0] = ld(ya, xa); t[1] = ld(ya, xb); t[2] = ld(yb, xa); t[3] = ld(yb, xb);
+        t[4] = ld(ya, xc); t[5] = ld(ya, xd); t[6] = ld(yb, xc); t[7] = ld(yb, xd);
+        t[8] = ld(yc, xa); t[9] = ld(yc, xb); t[10] = ld(yd, xa); t[11] = ld(yd, xb);
+        t[12] = ld(yc, xc); t[13] = ld(yc, xd); t[14] = ld(yd, xc); t[15] = ld(yd, xd);
+        // two channels per instruction: {w * lo16, w * hi16} in one or two instructions (mul_pair16), sums as v_pk_add_f32 --
+        // the IEEE results of the scalar forms, the reference's order (roi_align_cpu_loop.cpp:95-98)
+        f32x2 a[4];
 #pragma unroll
-        for (int i = 0; i < 8; i++) a[i] = 0.f;
+        for (int k = 0; k < 4; k++) a[k] = f32x2{0.f, 0.f};
 #pragma unroll
         for (int sidx = 0; sidx < 4; sidx++) {   // (iy, ix) = (0,0) (0,1) (1,0) (1,1): the reference's accumulation order
-          const AxisEntry& y = ax[sidx >> 1];
-          const AxisEntry& x = ax[2 + (sidx & 1)];
+          const AxisEntry& y = (sidx >> 1) ? y1e : y0e;
+          const AxisEntry& x = (sidx & 1) ? x1e : x0e;
           const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;
           const uint32_t* u1 = reinterpret_cast<const uint32_t*>(&t[sidx * 4]);
           const uint32_t* u2 = reinterpret_cast<const uint32_t*>(&t[sidx * 4 + 1]);
@@ -651,21 +679,20 @@ __global__ __launch_bounds__(kRoiAlignThreads) void roi_align_fwd_nhwc(RoiAlignP
           const uint32_t* u4 = reinterpret_cast<const uint32_t*>(&t[sidx * 4 + 3]);
 #pragma unroll
           for (int k = 0; k < 4; k++) {           // dword k holds channels 2k (low half) and 2k + 1 (high half)
-            a[2 * k] += w1 * lo16_to_f32<TIn>(u1[k]) + w2 * lo16_to_f32<TIn>(u2[k]) + w3 * lo16_to_f32<TIn>(u3[k]) + w4 * lo16_to_f32<TIn>(u4[k]);
-            a[2 * k + 1] += w1 * hi16_to_f32<TIn>(u1[k]) + w2 * hi16_to_f32<TIn>(u2[k]) + w3 * hi16_to_f32<TIn>(u3[k]) + w4 * hi16_to_f32<TIn>(u4[k]);
+            f32x2 s = mul_pair16<TIn>(u1[k], w1) + mul_pair16<TIn>(u2[k], w2);
+            s = s + mul_pair16<TIn>(u3[k], w3);
+            s = s + mul_pair16<TIn>(u4[k], w4);
+            a[k] = a[k] + s;
           }
         }
         float* so = slab + (8 * q8) * bins + bin;
 #pragma unroll
-        for (int i = 0; i < 8; i++) so[i * bins] = a[i] * inv_count;
-      };
-      // (requesting the taps of both bins of a lane before pooling either -- one round trip per workgroup, 160 VGPRs, three waves per
-      //  SIMD -- was measured slower: 0.274 ms against 0.242 for the box-head launch)
-      for (int bin = slot8; bin < bins; bin += kRoiAlignThreads / NQ8) {
-        uint4 t[16];
-        AxisEntry ax[4];
-        taps(bin, t, ax);
-        pool(bin, t, ax);
+        for (int k = 0; k < 4; k++) {
+          const f32x2 o = a[k] * inv_count;
+          so[(2 * k) * bins] = o.x; so[(2 * k + 1) * bins] = o.y;
+        }
+        ph += step_h; pw += step_w;
+        if (pw >= p.pooled_w) { pw -= p.pooled_w; ph++; }
       }
       __syncthreads();
       store_slab_vec<TOut, kRoiAlignThreads>(out, slab, nc * bins, tid);
