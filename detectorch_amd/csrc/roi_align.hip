@@ -551,23 +551,6 @@ template <> __device__ __forceinline__ float hi16_to_f32<bf16_t>(uint32_t w) { r
 template <> __device__ __forceinline__ float lo16_to_f32<float>(uint32_t w) { return 0.f; }      // never instantiated for float maps
 template <> __device__ __forceinline__ float hi16_to_f32<float>(uint32_t w) { return 0.f; }
 
-// {w * float(low half), w * float(high half)} of a dword of two 16-bit elements, as a register pair for the packed fp32 adds.
-// fp16: v_fma_mix_f32 converts and multiplies in ONE instruction -- fma(float(x), w, -0.0) is round(float(x) * w), the value
-// v_cvt_f32_f16 + v_mul_f32 give (adding -0 never changes a sum).  bf16: two bit operations, one v_pk_mul_f32.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <typename T> __device__ __forceinline__ f32x2 mul_pair16(uint32_t u, float w);
-template <> __device__ __forceinline__ f32x2 mul_pair16<__half>(uint32_t u, float w) {
-  f32x2 r;
-  asm("v_fma_mix_f32 %0, %2, %3, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, %3, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-      : "=&v"(r.x), "=&v"(r.y) : "v"(u), "v"(w), "s"(-0.0f));
-  return r;
-}
-template <> __device__ __forceinline__ f32x2 mul_pair16<bf16_t>(uint32_t u, float w) {
-  const f32x2 v = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
-  return v * w;
-}
-template <> __device__ __forceinline__ f32x2 mul_pair16<float>(uint32_t, float) { return f32x2{0.f, 0.f}; }   // never instantiated for float maps
-
 // [n_out] float32 slab -> contiguous output of type TOut: 16-byte stores where the alignment allows (4 floats, or 8 16-bit values
 // rounded exactly as from_f32 does element by element); a 2-byte store per element cost 12 x the time per byte
 template <typename TOut, int THREADS>
@@ -903,7 +886,10 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   // channels_last, sampling_ratio 2, <= 64 bins: window staged with LDS-DMA, conflict-free tap reads (roi_align_nhwc.hip)
   if (all_nhwc && !cfg.general && cfg.nhwc_direct && dtc::roi_align_nhwc_lds_supported(p, in_dtype, out_dtype))
     return dtc::launch_roi_align_nhwc_lds(p, in_dtype, out_dtype, s);
-  // 16-bit channels_last maps, 2 x 2 samples: the direct kernel's 8-channel lanes (16-byte tap loads) for every bin count
+  // 16-bit channels_last maps, 2 x 2 samples: 8-channel lanes, the bins of several RoIs flattened over a workgroup (roi_align_nhwc16.hip)
+  if (all_nhwc && !cfg.general && cfg.nhwc_direct && dtc::roi_align_nhwc16_supported(p, in_dtype, out_dtype))
+    return dtc::launch_roi_align_nhwc16(p, in_dtype, out_dtype, s);
+  // ... or one RoI per workgroup when that kernel's alignment / size conditions do not hold
   const bool wide16 = in_dtype != DTC_F32 && sampling_ratio == 2 && channels % 32 == 0;
   if (lds_ok && all_nhwc && (few_taps || wide16) && cfg.nhwc_direct) return dtc::launch_typed(dtc::kKernNhwc, p, in_dtype, out_dtype, s);
   // one level whose whole map fits LDS (the C4 heads), adaptive sampling: the map-stationary kernel (roi_align_map.hip)

@@ -113,6 +113,23 @@ __device__ __forceinline__ RoiHead load_roi_head(const RoiAlignParams& p, int ri
   return roi_head_from_raw(p, load_roi_raw(p, ri));
 }
 
+// {w * float(low half), w * float(high half)} of a dword of two 16-bit elements, as a register pair for the packed fp32 adds.
+// fp16: v_fma_mix_f32 converts and multiplies in ONE instruction -- fma(float(x), w, -0.0) is round(float(x) * w), the value
+// v_cvt_f32_f16 + v_mul_f32 give (adding -0 never changes a sum).  bf16: two bit operations, one v_pk_mul_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ f32x2 mul_pair16(uint32_t u, float w);
+template <> __device__ __forceinline__ f32x2 mul_pair16<__half>(uint32_t u, float w) {
+  f32x2 r;
+  asm("v_fma_mix_f32 %0, %2, %3, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, %3, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(r.x), "=&v"(r.y) : "v"(u), "v"(w), "s"(-0.0f));
+  return r;
+}
+template <> __device__ __forceinline__ f32x2 mul_pair16<bf16_t>(uint32_t u, float w) {
+  const f32x2 v = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+  return v * w;
+}
+template <> __device__ __forceinline__ f32x2 mul_pair16<float>(uint32_t, float) { return f32x2{0.f, 0.f}; }   // never instantiated for float maps
+
 // launchers of the cluster-stationary kernel (roi_align_tile.hip); in_dtype / out_dtype are DTC_* codes
 bool roi_align_tile_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
 int launch_roi_align_tile(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream);
@@ -127,5 +144,9 @@ int launch_roi_align_map_ws(const RoiAlignParams& p, int in_dtype, int out_dtype
 // launchers of the channels_last kernel with an LDS-DMA staged window (roi_align_nhwc.hip): sampling_ratio 2, <= 64 bins
 bool roi_align_nhwc_lds_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
 int launch_roi_align_nhwc_lds(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream);
+
+// launchers of the grouped 16-bit channels_last kernel (roi_align_nhwc16.hip): sampling_ratio 2, bins of several RoIs flattened over the lanes
+bool roi_align_nhwc16_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
+int launch_roi_align_nhwc16(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream);
 
 }  // namespace dtc

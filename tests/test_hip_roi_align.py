@@ -444,6 +444,48 @@ def test_nhwc_16bit_direct_kernel_wide_lanes_vs_oracle(hip, oracle, dtype, C, ph
     assert torch.equal(out16.cpu(), torch.from_numpy(ref).to(tdt))
 
 
+@pytest.mark.parametrize("dtype,ph,far", [("f16", 7, False), ("bf16", 7, True), ("f16", 14, True), ("bf16", 14, False)])
+def test_nhwc16_grouped_kernel_padding_rows_tail_groups_and_far_levels(hip, oracle, dtype, ph, far):
+    """roi_align_nhwc16.hip (16-bit channels_last maps, the bins of up to four RoIs dealt over one workgroup): padding rows
+    (level -1 -> zeros) inside and at the end of a group, a RoI count that leaves a partial last group, a permuted visiting order,
+    and -- far -- levels carved from the two ends of one 5 GB allocation, so that the upper ones lie more than 4 GB above the
+    launch's base address and their workgroups take the 64-bit address loop.  Bit-exact against the oracle on the up-cast maps."""
+    C = 128
+    feats, rois5, lv = _nhwc_case(oracle, C, 77 + ph, R=117)
+    lv = lv.copy()
+    lv[[3, 4, 5, 50, rois5.shape[0] - 1]] = -1
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    if far:
+        big = torch.empty(int(2.6e9), dtype=tdt, device="cuda")          # 5.2 GB
+        tf, pos = [], 0
+        for i, f in enumerate(feats):
+            n, c, h, w = f.shape
+            cnt = n * c * h * w
+            if i < 2:
+                flat = big[pos:pos + cnt]; pos += (cnt + 63) // 64 * 64
+            else:
+                end = big.numel() - (i - 2) * 8 * 1024 * 1024
+                flat = big[end - cnt:end]
+            v = flat.view(n, h, w, c).permute(0, 3, 1, 2)
+            v.copy_(cu(f).to(tdt))
+            assert v.stride(1) == 1
+            tf.append(v)
+        assert tf[3].data_ptr() - tf[0].data_ptr() > (1 << 32)
+    else:
+        tf = [cu(f).to(tdt).contiguous(memory_format=torch.channels_last) for f in feats]
+    up = [t.float().contiguous().cpu().numpy() for t in tf]
+    ref = np.zeros((rois5.shape[0], C, ph, ph), np.float32)
+    for l in range(4):
+        m = lv == l
+        if m.any():
+            ref[m] = oracle.roi_align_forward(up[l], rois5[m], ph, ph, synth.FPN_ROI_SCALES[l], 2)
+    out = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, cu(rois5), ph, ph, 2, roi_levels=cu(lv))
+    assert out.dtype == torch.float32 and np.array_equal(out.cpu().numpy(), ref)
+    order = torch.randperm(rois5.shape[0], generator=torch.Generator().manual_seed(5)).to(torch.int32)
+    out16 = hip.roi_align_forward(tf, synth.FPN_ROI_SCALES, cu(rois5), ph, ph, 2, roi_levels=cu(lv), roi_order=order.cuda(), out_dtype=tdt)
+    assert torch.equal(out16.cpu(), torch.from_numpy(ref).to(tdt))
+
+
 @pytest.mark.parametrize("dtype,C", [("f32", 64), ("f32", 256), ("f16", 128), ("bf16", 256)])
 def test_nhwc_lds_dma_kernel_vs_oracle(hip, oracle, dtype, C):
     """channels_last feature maps, 7x7 bins, sampling ratio 2: window staged with LDS-DMA, lane <-> channel chunk.  Small boxes
@@ -476,7 +518,7 @@ sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle")); sys.
 import oracle as orc
 from detectorch_amd import hip, synth
 import test_hip_roi_align as T
-sixteen = os.environ.get("DTC_RA_NHWC_LDS_16BIT") or os.environ.get("DTC_RA_NHWC_PIPE16")
+sixteen = os.environ.get("DTC_RA_NHWC_LDS_16BIT") or os.environ.get("DTC_RA_NHWC_PIPE16") or os.environ.get("DTC_RA_NHWC16")
 for ph in (7, 14):
     for tdt, C in ((torch.float32, 64),) + (((torch.float16, 128), (torch.bfloat16, 256)) if sixteen else ()):
         feats, rois5, lv = T._nhwc_case(orc, C, 5 + ph, R=260 if ph == 7 else 120)
@@ -504,12 +546,13 @@ print("ok")
                                  "DTC_RA_NHWC_LDS_16BIT=1", "DTC_RA_NHWC_LDS_16BIT=1 DTC_RA_NHWC_LDS_KB=24",
                                  "DTC_RA_NHWC_PIPE=2", "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_LDS_KB=30", "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_LDS_KB=156",
                                  "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_PIPE16=1", "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_PIPE16=1 DTC_RA_NHWC_LDS_KB=40",
-                                 "DTC_RA_NHWC_PIPE=0"])
+                                 "DTC_RA_NHWC_PIPE=0", "DTC_RA_NHWC16=0"])
 def test_nhwc_lds_image_sizes_in_child_process(hip, oracle, env):
     """The LDS image size decides how many strips a window takes (24 KB: nearly every RoI in several strips or straight from
     global; 156 KB: one workgroup per CU, one strip) -- and must not change a bit; DTC_RA_NHWC_LDS=0 is the direct-gather kernel.
     DTC_RA_NHWC_PIPE=2: the pipelined kernel (round 4) for 7 x 7 bins too (by default it takes the 14 x 14 launches only), at
     image sizes from a handful of pixels to one workgroup per CU, float32 and 16-bit maps; =0: the round-3 kernels everywhere.
+    DTC_RA_NHWC16=0: 16-bit maps through the one-RoI-per-workgroup direct kernel instead of the grouped one (roi_align_nhwc16.hip).
     Every case: 7 x 7 and 14 x 14 bins, identity and permuted visiting order."""
     import os
     import subprocess
