@@ -20,7 +20,7 @@ def strip(src):
 
 
 # channels_last feature maps (bench.py --channels-last) are pooled by the kernels of these files whatever the workload
-NHWC_FILES = ["roi_align.hip", "roi_align_nhwc.hip", "roi_align_common.h"]
+NHWC_FILES = ["roi_align.hip", "roi_align_nhwc.hip", "roi_align_nhwc16.hip", "roi_align_common.h"]
 
 
 def kernel_sha16(workload, channels_last=False):
