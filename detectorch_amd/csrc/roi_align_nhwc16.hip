@@ -20,7 +20,7 @@
 namespace dtc {
 
 #ifndef N16_MIN_WG
-#define N16_MIN_WG 5
+#define N16_MIN_WG 1
 #endif
 constexpr int kN16Threads = 256;
 constexpr int kN16MaxG = 8;
@@ -35,6 +35,13 @@ struct N16Tab { uint32_t lo, hi; float l, h; };     // byte offsets inside the i
 
 template <typename TOut> __device__ __forceinline__ void n16_put(TOut* d, float v) { *d = from_f32<TOut>(v); }
 
+// channel pair k of a 16-byte tap load times the tap weight: 16-bit maps hold 4 pairs per load (one dword each), float32 maps 2
+template <typename TIn> __device__ __forceinline__ f32x2 n16_tap_pair(const uint32_t* u, int k, float w) { return mul_pair16<TIn>(u[k], w); }
+template <> __device__ __forceinline__ f32x2 n16_tap_pair<float>(const uint32_t* u, int k, float w) {
+  const f32x2 v = {__uint_as_float(u[2 * k]), __uint_as_float(u[2 * k + 1])};
+  return v * w;
+}
+
 // the 16 taps of one bin (8 channels each) and the pooled 8 channels -> slab.  ADDR: callable (y_off, x_off) -> uint4
 template <typename TIn, typename TOut, typename LD>
 __device__ __forceinline__ void n16_pool_bin(const N16Tab& y0e, const N16Tab& y1e, const N16Tab& x0e, const N16Tab& x1e, LD ld,
@@ -45,9 +52,10 @@ __device__ __forceinline__ void n16_pool_bin(const N16Tab& y0e, const N16Tab& y1
   t[8] = ld(y1e.lo, x0e.lo); t[9] = ld(y1e.lo, x0e.hi); t[10] = ld(y1e.hi, x0e.lo); t[11] = ld(y1e.hi, x0e.hi);
   t[12] = ld(y1e.lo, x1e.lo); t[13] = ld(y1e.lo, x1e.hi); t[14] = ld(y1e.hi, x1e.lo); t[15] = ld(y1e.hi, x1e.hi);
   __builtin_amdgcn_sched_barrier(0);      // keep the 16 loads ahead of the arithmetic (the scheduler otherwise interleaves them to save registers)
-  f32x2 a[4];
+  constexpr int PP = 8 / (int)sizeof(TIn);      // channel pairs per lane: 4 (16-bit maps, 8 channels) or 2 (float32 maps, 4 channels)
+  f32x2 a[PP];
 #pragma unroll
-  for (int k = 0; k < 4; k++) a[k] = f32x2{0.f, 0.f};
+  for (int k = 0; k < PP; k++) a[k] = f32x2{0.f, 0.f};
 #pragma unroll
   for (int sidx = 0; sidx < 4; sidx++) {   // (iy, ix) = (0,0) (0,1) (1,0) (1,1): the reference's accumulation order
     const N16Tab& y = (sidx >> 1) ? y1e : y0e;
@@ -58,15 +66,15 @@ __device__ __forceinline__ void n16_pool_bin(const N16Tab& y0e, const N16Tab& y1
     const uint32_t* u3 = reinterpret_cast<const uint32_t*>(&t[sidx * 4 + 2]);
     const uint32_t* u4 = reinterpret_cast<const uint32_t*>(&t[sidx * 4 + 3]);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {           // dword k holds channels 2k (low half) and 2k + 1 (high half)
-      f32x2 s = mul_pair16<TIn>(u1[k], w1) + mul_pair16<TIn>(u2[k], w2);
-      s = s + mul_pair16<TIn>(u3[k], w3);
-      s = s + mul_pair16<TIn>(u4[k], w4);
+    for (int k = 0; k < PP; k++) {          // pair k: channels 2k and 2k + 1 of the lane
+      f32x2 s = n16_tap_pair<TIn>(u1, k, w1) + n16_tap_pair<TIn>(u2, k, w2);
+      s = s + n16_tap_pair<TIn>(u3, k, w3);
+      s = s + n16_tap_pair<TIn>(u4, k, w4);
       a[k] = a[k] + s;
     }
   }
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < PP; k++) {
     const f32x2 o = a[k] * 0.25f;           // / count, count = 4 (:216)
     n16_put<TOut>(so + (2 * k) * bins, o.x); n16_put<TOut>(so + (2 * k + 1) * bins, o.y);
   }
@@ -81,6 +89,7 @@ __global__ __launch_bounds__(kN16Threads, N16_MIN_WG) void roi_align_fwd_nhwc16(
   N16Roi* rinfo = reinterpret_cast<N16Roi*>(smem);
   N16Tab* tabs = reinterpret_cast<N16Tab*>(smem + kN16MaxG * sizeof(N16Roi));
   TOut* slab = reinterpret_cast<TOut*>(smem + kN16MaxG * sizeof(N16Roi) + (size_t)G * ne * sizeof(N16Tab));
+  constexpr int ESZ = (int)sizeof(TIn), CPL = 16 / ESZ;      // bytes per element; channels per lane (one 16-byte load per tap)
   const int tid = threadIdx.x;
   const int nct = p.channels / CB;
   const int wi = xcd_work_item(blockIdx.x, gridDim.x, p.xcd_remap);
@@ -100,12 +109,12 @@ __global__ __launch_bounds__(kN16Threads, N16_MIN_WG) void roi_align_fwd_nhwc16(
       const bool isy = e < ny;
       const int u = isy ? e : e - ny;
       const AxisEntry a = isy ? make_axis(hd.sh, hd.bin_h, u >> 1, u & 1, 2, L.height) : make_axis(hd.sw, hd.bin_w, u >> 1, u & 1, 2, L.width);
-      const uint32_t sb = 2u * (uint32_t)(isy ? L.stride_h : L.stride_w);
+      const uint32_t sb = (uint32_t)ESZ * (uint32_t)(isy ? L.stride_h : L.stride_w);
       o.lo = (uint32_t)a.lo * sb; o.hi = (uint32_t)a.hi * sb; o.l = a.l; o.h = a.h;
       if (e == 0) {
-        const char* img = reinterpret_cast<const char*>(L.data) + 2 * (int64_t)hd.b * L.stride_n;
+        const char* img = reinterpret_cast<const char*>(L.data) + ESZ * (int64_t)hd.b * L.stride_n;
         const uint64_t delta = (uint64_t)(img - base0);
-        const uint64_t ext = 2ull * ((uint64_t)L.stride_h * (uint64_t)L.height + (uint64_t)L.stride_w * (uint64_t)L.width + (uint64_t)p.channels);
+        const uint64_t ext = (uint64_t)ESZ * ((uint64_t)L.stride_h * (uint64_t)L.height + (uint64_t)L.stride_w * (uint64_t)L.width + (uint64_t)p.channels);
         info.lvl = hd.lvl; info.ptr = img;
         info.far = (delta + ext) >= (1ull << 32) ? 1u : 0u;
         info.rebase = (uint32_t)delta;
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(kN16Threads, N16_MIN_WG) void roi_align_fwd_nhwc16(
   any_far = __builtin_amdgcn_readfirstlane((int)any_far) != 0;
 
   // ---- B. bins of all RoIs of the group, dealt over the lanes: item = slot, slot + kStep, ... ---------------------------------
-  constexpr int NQ8 = CB / 8, kStep = kN16Threads / NQ8;
+  constexpr int NQ8 = CB / CPL, kStep = kN16Threads / NQ8;      // lanes per bin; bins per round
   const int q8 = tid % NQ8, slot = tid / NQ8;
   const int items = ng * bins;
   // (RoI, bin row, bin column) of the lane's item as a mixed-radix counter: no division per round
@@ -130,19 +139,19 @@ __global__ __launch_bounds__(kN16Threads, N16_MIN_WG) void roi_align_fwd_nhwc16(
   int ph, pw;
   { const int bin = slot - rl * bins; ph = bin / p.pooled_w; pw = bin - ph * p.pooled_w; }
   const uint32_t lane_off = 16u * (uint32_t)q8;
-  const char* sbase = base0 + 2 * c0;                                  // scalar: near RoIs
+  const char* sbase = base0 + ESZ * c0;                                  // scalar: near RoIs
   auto pool_items = [&](auto far_tag) {
     constexpr bool FAR = decltype(far_tag)::value;
     for (int it = slot; it < items; it += kStep) {
       const N16Tab* tab = tabs + rl * ne;
       const N16Tab y0e = tab[2 * ph], y1e = tab[2 * ph + 1], x0e = tab[ny + 2 * pw], x1e = tab[ny + 2 * pw + 1];
       const N16Roi info = rinfo[rl];
-      TOut* so = slab + ((size_t)rl * CB + 8 * q8) * bins + (ph * p.pooled_w + pw);
+      TOut* so = slab + ((size_t)rl * CB + CPL * q8) * bins + (ph * p.pooled_w + pw);
       if (info.lvl < 0) {            // padding row of a fixed-shape batch: defined output
 #pragma unroll
-        for (int k = 0; k < 8; k++) n16_put<TOut>(so + k * bins, 0.f);
+        for (int k = 0; k < CPL; k++) n16_put<TOut>(so + k * bins, 0.f);
       } else if constexpr (FAR) {
-        const char* lbase = info.ptr + 2 * c0 + lane_off;
+        const char* lbase = info.ptr + ESZ * c0 + lane_off;
         n16_pool_bin<TIn, TOut>(y0e, y1e, x0e, x1e, [&](uint32_t yo, uint32_t xo) { return *reinterpret_cast<const uint4*>(lbase + (yo + xo)); }, so, bins);
       } else {
         const uint32_t lo = info.rebase + lane_off;
@@ -170,6 +179,10 @@ static bool n16_enabled() {      // A/B: DTC_RA_NHWC16=0 sends 16-bit channels_l
   static const bool on = [] { const char* e = getenv("DTC_RA_NHWC16"); return !(e && e[0] == '0'); }();
   return on;
 }
+static bool n16_f32() {          // DTC_RA_NHWC_DIRECT32=0: float32 channels_last maps with <= 64 bins stay on the LDS-DMA kernels (roi_align_nhwc.hip)
+  static const bool on = [] { const char* e = getenv("DTC_RA_NHWC_DIRECT32"); return !(e && e[0] == '0'); }();
+  return on;
+}
 static int n16_out_size(int out_dtype) { return out_dtype == DTC_F32 ? 4 : 2; }
 static int n16_cb(const RoiAlignParams& p, int out_dtype) {
   const long long per64 = 64ll * p.pooled_h * p.pooled_w * n16_out_size(out_dtype);
@@ -177,15 +190,21 @@ static int n16_cb(const RoiAlignParams& p, int out_dtype) {
 }
 
 bool roi_align_nhwc16_supported(const RoiAlignParams& p, int in_dtype, int out_dtype) {
-  if (!n16_enabled() || (in_dtype != DTC_F16 && in_dtype != DTC_BF16) || p.sampling_ratio != 2 || p.n_rois < 1) return false;
+  if (!n16_enabled() || p.sampling_ratio != 2 || p.n_rois < 1) return false;
+  // float32 maps: 4-channel lanes.  Measured against the LDS-DMA kernels (tools/r04/README.md section 6): box head 0.375 against 0.393 ms on
+  // the bench RoIs and 0.40 against 0.51 on the harder set (no window to stage: the cost does not depend on the RoI size); the
+  // 14 x 14 mask head 0.148 against 0.130 -> taken for <= 64 bins only
+  if (in_dtype == DTC_F32) { if (!n16_f32() || out_dtype != DTC_F32 || p.pooled_h * p.pooled_w > 64) return false; }
+  else if (in_dtype != DTC_F16 && in_dtype != DTC_BF16) return false;
   if (out_dtype != DTC_F32 && out_dtype != in_dtype) return false;
+  const int epl = in_dtype == DTC_F32 ? 4 : 8;          // elements per 16-byte load
   const int cb = n16_cb(p, out_dtype), bins = p.pooled_h * p.pooled_w, osz = n16_out_size(out_dtype);
   if (p.channels % cb != 0 || (long long)cb * bins * osz > kN16SlabBytes || ((long long)cb * bins * osz) % 16 != 0) return false;
   if (((long long)p.channels * bins * osz) % 16 != 0 || (reinterpret_cast<uintptr_t>(p.out) & 15) != 0) return false;
   if (2 * (p.pooled_h + p.pooled_w) > 256) return false;
   for (int i = 0; i < p.n_levels; i++) {
     const dtc_feat_level& L = p.lv[i];
-    if (L.stride_c != 1 || ((L.stride_h | L.stride_w | L.stride_n) & 7) != 0 || (reinterpret_cast<uintptr_t>(L.data) & 15) != 0) return false;
+    if (L.stride_c != 1 || ((L.stride_h | L.stride_w | L.stride_n) & (epl - 1)) != 0 || (reinterpret_cast<uintptr_t>(L.data) & 15) != 0) return false;
     if (L.stride_h < 0 || L.stride_w < 0 || L.stride_n < 0) return false;
     if ((long long)L.stride_h * L.height + (long long)L.stride_w * L.width + p.channels >= (1ll << 30)) return false;   // 32-bit byte offsets inside an image
   }
@@ -214,6 +233,7 @@ static int launch_n16_cb(const RoiAlignParams& p, int cb, hipStream_t stream) {
 
 int launch_roi_align_nhwc16(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream) {
   const int cb = n16_cb(p, out_dtype);
+  if (in_dtype == DTC_F32 && out_dtype == DTC_F32) return launch_n16_cb<float, float>(p, cb, stream);
   if (in_dtype == DTC_F16 && out_dtype == DTC_F16) return launch_n16_cb<__half, __half>(p, cb, stream);
   if (in_dtype == DTC_F16 && out_dtype == DTC_F32) return launch_n16_cb<__half, float>(p, cb, stream);
   if (in_dtype == DTC_BF16 && out_dtype == DTC_BF16) return launch_n16_cb<bf16_t, bf16_t>(p, cb, stream);

@@ -518,7 +518,8 @@ sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle")); sys.
 import oracle as orc
 from detectorch_amd import hip, synth
 import test_hip_roi_align as T
-sixteen = os.environ.get("DTC_RA_NHWC_LDS_16BIT") or os.environ.get("DTC_RA_NHWC_PIPE16") or os.environ.get("DTC_RA_NHWC16")
+sixteen = (os.environ.get("DTC_RA_NHWC_LDS_16BIT") or os.environ.get("DTC_RA_NHWC_PIPE16")
+           or ("DTC_RA_NHWC16" in os.environ and "DTC_RA_NHWC_DIRECT32" not in os.environ))
 for ph in (7, 14):
     for tdt, C in ((torch.float32, 64),) + (((torch.float16, 128), (torch.bfloat16, 256)) if sixteen else ()):
         feats, rois5, lv = T._nhwc_case(orc, C, 5 + ph, R=260 if ph == 7 else 120)
@@ -542,17 +543,22 @@ print("ok")
 """
 
 
-@pytest.mark.parametrize("env", ["DTC_RA_NHWC_LDS_KB=24", "DTC_RA_NHWC_LDS_KB=78", "DTC_RA_NHWC_LDS_KB=156", "DTC_RA_NHWC_LDS=0",
-                                 "DTC_RA_NHWC_LDS_16BIT=1", "DTC_RA_NHWC_LDS_16BIT=1 DTC_RA_NHWC_LDS_KB=24",
-                                 "DTC_RA_NHWC_PIPE=2", "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_LDS_KB=30", "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_LDS_KB=156",
-                                 "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_PIPE16=1", "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_PIPE16=1 DTC_RA_NHWC_LDS_KB=40",
-                                 "DTC_RA_NHWC_PIPE=0", "DTC_RA_NHWC16=0"])
+_D0 = "DTC_RA_NHWC_DIRECT32=0 DTC_RA_NHWC16=0 "        # float32 and 16-bit maps past the grouped direct kernel: the kernels of roi_align_nhwc.hip / roi_align.hip
+
+
+@pytest.mark.parametrize("env", [_D0 + "DTC_RA_NHWC_LDS_KB=24", _D0 + "DTC_RA_NHWC_LDS_KB=78", _D0 + "DTC_RA_NHWC_LDS_KB=156", _D0 + "DTC_RA_NHWC_LDS=0",
+                                 _D0 + "DTC_RA_NHWC_LDS_16BIT=1", _D0 + "DTC_RA_NHWC_LDS_16BIT=1 DTC_RA_NHWC_LDS_KB=24",
+                                 _D0 + "DTC_RA_NHWC_PIPE=2", _D0 + "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_LDS_KB=30", _D0 + "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_LDS_KB=156",
+                                 _D0 + "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_PIPE16=1", _D0 + "DTC_RA_NHWC_PIPE=2 DTC_RA_NHWC_PIPE16=1 DTC_RA_NHWC_LDS_KB=40",
+                                 _D0 + "DTC_RA_NHWC_PIPE=0", "DTC_RA_NHWC16=0", "DTC_RA_NHWC_DIRECT32=0", "DTC_RA_NHWC16=1"])
 def test_nhwc_lds_image_sizes_in_child_process(hip, oracle, env):
     """The LDS image size decides how many strips a window takes (24 KB: nearly every RoI in several strips or straight from
     global; 156 KB: one workgroup per CU, one strip) -- and must not change a bit; DTC_RA_NHWC_LDS=0 is the direct-gather kernel.
     DTC_RA_NHWC_PIPE=2: the pipelined kernel (round 4) for 7 x 7 bins too (by default it takes the 14 x 14 launches only), at
     image sizes from a handful of pixels to one workgroup per CU, float32 and 16-bit maps; =0: the round-3 kernels everywhere.
     DTC_RA_NHWC16=0: 16-bit maps through the one-RoI-per-workgroup direct kernel instead of the grouped one (roi_align_nhwc16.hip).
+    DTC_RA_NHWC_DIRECT32=0: float32 maps with <= 64 bins on the LDS-DMA kernels instead of the grouped direct kernel (4-channel lanes);
+    the LDS-kernel settings above carry both switches so that they reach the kernels they size.  DTC_RA_NHWC16=1: the defaults, 16-bit maps included.
     Every case: 7 x 7 and 14 x 14 bins, identity and permuted visiting order."""
     import os
     import subprocess
