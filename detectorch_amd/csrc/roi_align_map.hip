@@ -91,7 +91,7 @@ __device__ __forceinline__ int map_uni(int v) { return __builtin_amdgcn_readfirs
 // outside the sample loops).  hdr[]: word k is fetched by lane k and read with readlane.
 enum { kMhR = 0, kMhB, kMhFlags, kMhGh, kMhGw, kMhInv, kMhCount, kMhRcpLo, kMhRcpHi, kMhSh, kMhSw, kMhBinH, kMhBinW, kMhWords = 64 };
 enum { kMfPad = 1, kMfYtab = 2, kMfXtab = 4, kMfMerged = 8 };
-struct MapAxis { int32_t lo, hi; float l, h; };            // lo / hi: LDS byte offsets (row * W * 16, column * 16)
+struct MapAxis { int32_t lo, hi; float l, h; };            // lo / hi: LDS byte offsets (row * pitch * 16, column * 16)
 struct MapPrepRoi { uint32_t hdr[kMhWords]; MapAxis y[64]; MapAxis x[64]; };    // 256 + 2 x 1024 B
 static_assert(sizeof(MapPrepRoi) == 2304, "MapPrepRoi layout");
 
@@ -120,7 +120,7 @@ __device__ __forceinline__ MapAxis map_merged_entry(const RoiHead& hd, int lane,
   return a;
 }
 
-__global__ __launch_bounds__(256) void map_prep_kernel(RoiAlignParams p, MapPrepRoi* __restrict__ prep, int fast) {
+__global__ __launch_bounds__(256) void map_prep_kernel(RoiAlignParams p, MapPrepRoi* __restrict__ prep, int fast, int pitch) {
   const int ri = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (ri >= p.n_rois) return;
   const RoiHead hd = roi_head_from_raw(p, load_roi_raw(p, ri));
@@ -139,14 +139,14 @@ __global__ __launch_bounds__(256) void map_prep_kernel(RoiAlignParams p, MapPrep
     merged = __ballot(!fits) == 0ull;
   }
   if (merged) {
-    T->y[lane] = map_merged_entry<true>(hd, lane, gh, p.pooled_h, H, W * 16);
+    T->y[lane] = map_merged_entry<true>(hd, lane, gh, p.pooled_h, H, pitch * 16);
     T->x[lane] = map_merged_entry<false>(hd, lane, gw, p.pooled_w, W, 16);
   } else if (!padrow) {
     // entry e = (bin e / g, sample e % g) by lane e: (lane + .5) * (1 / g) truncated is exact (>= .5 / g away from an integer)
     const int qy = (int)(((float)lane + 0.5f) * __frcp_rn((float)gh)), qx = (int)(((float)lane + 0.5f) * __frcp_rn((float)gw));
     const AxisEntry ey = make_axis(hd.sh, hd.bin_h, min(qy, p.pooled_h - 1), lane - qy * gh, gh, H);
     const AxisEntry ex = make_axis(hd.sw, hd.bin_w, min(qx, p.pooled_w - 1), lane - qx * gw, gw, W);
-    MapAxis ay; ay.lo = ey.lo * W * 16; ay.hi = ey.hi * W * 16; ay.l = ey.l; ay.h = ey.h;
+    MapAxis ay; ay.lo = ey.lo * pitch * 16; ay.hi = ey.hi * pitch * 16; ay.l = ey.l; ay.h = ey.h;
     MapAxis ax; ax.lo = ex.lo << 4; ax.hi = ex.hi << 4; ax.l = ex.l; ax.h = ex.h;
     T->y[lane] = ay; T->x[lane] = ax;
   }
@@ -174,14 +174,17 @@ __global__ __launch_bounds__(256) void map_prep_kernel(RoiAlignParams p, MapPrep
 struct MapRec { RoiRaw raw; uint32_t hw; MapAxis ay, ax; };       // what a wave holds of a RoI: its descriptor, or its prepared record
 
 template <typename TIn, typename TOut, int NQ, bool PREP>
-__global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams p, int seg_len, int use_slab) {
+__global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams p, int seg_len, int use_slab, int pitch) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int pend_idx[kMapWaves];
   __shared__ int pend_img[kMapWaves];
   __shared__ int s_next;                                          // next RoI of the run nobody has taken yet
   const dtc_feat_level L = p.lv[0];
   const int H = L.height, W = L.width, HW = H * W;
-  const int plane_bytes = HW * 16;
+  // rows of the LDS image are `pitch` slots apart: W, or W + 1 when W is even (map_pitch) -- an odd pitch spreads the rows of a
+  // RoI's bins over the 16 slots a ds_read_b128 lane group can read at once (simulated on RPN-like boxes, tools/r04/lds_map_sim.py:
+  // 9.8 -> 8.7 LDS cycles per tap read on the 84-column res4 map)
+  const int plane_bytes = H * pitch * 16;
   const char* map = reinterpret_cast<const char*>(smem);          // [NQ][H*W][4 channels] float32
   float* mapw = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
         const int qy = (int)(((float)lane + 0.5f) * __frcp_rn((float)gh)), qx = (int)(((float)lane + 0.5f) * __frcp_rn((float)gw));
         ey = make_axis(sh, bin_h, min(qy, p.pooled_h - 1), lane - qy * gh, gh, H);
         ex = make_axis(sw, bin_w, min(qx, p.pooled_w - 1), lane - qx * gw, gw, W);
-        ey_lo = ey.lo * W * 16; ey_hi = ey.hi * W * 16; ex_lo = ex.lo << 4; ex_hi = ex.hi << 4;
+        ey_lo = ey.lo * pitch * 16; ey_hi = ey.hi * pitch * 16; ex_lo = ex.lo << 4; ex_hi = ex.hi << 4;
       }
 #pragma unroll 1
       for (int b0 = 0; b0 < bins; b0 += 64) {
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
             ylo = __shfl(ey_lo, src, 64); yhi = __shfl(ey_hi, src, 64); yl = __shfl(ey.l, src, 64); yh = __shfl(ey.h, src, 64);
           } else {
             const AxisEntry y = make_axis(sh, bin_h, ph, iy, gh, H);
-            ylo = y.lo * W * 16; yhi = y.hi * W * 16; yl = y.l; yh = y.h;
+            ylo = y.lo * pitch * 16; yhi = y.hi * pitch * 16; yl = y.l; yh = y.h;
           }
 #pragma unroll 1
           for (int ix = 0; ix < gw; ix++) {
@@ -370,6 +373,9 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
     const bool vec4 = rows_contig && (HW & 3) == 0 && ((L.stride_c | L.stride_n) & 3) == 0 &&
                       (reinterpret_cast<uintptr_t>(L.data) & (4 * sizeof(TIn) - 1)) == 0;
     constexpr int SU = 4;                                             // loads in flight per thread
+    const int pad = pitch - W;                                         // LDS slot of map pixel px = px + (px / W) * pad
+    const float rcpw = __frcp_rn((float)W);
+    auto slot_of = [&](int px) { return px + (int)(((float)px + 0.5f) * rcpw) * pad; };     // px / W exact: px < 2^16, >= 0.5 / W from an integer
     if (vec4) {                                                       // a plane is one contiguous run: 4 pixels per load
       const int n4 = HW >> 2, total = CG * n4;
       for (int base = tid; base < total; base += SU * kMapThreads) {
@@ -385,8 +391,13 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
           const int e = base + u * kMapThreads;
           if (e < total) {
             const int c = e / n4, g = e - c * n4;
-            float* d = mapw + ((size_t)(c >> 2) * HW + 4 * g) * 4 + (c & 3);
-            d[0] = v[u].x; d[4] = v[u].y; d[8] = v[u].z; d[12] = v[u].w;
+            float* d = mapw + (size_t)(c >> 2) * (plane_bytes >> 2) + (c & 3);
+            if ((W & 3) == 0) {             // the four pixels of a load lie in one row
+              d += slot_of(4 * g) * 4;
+              d[0] = v[u].x; d[4] = v[u].y; d[8] = v[u].z; d[12] = v[u].w;
+            } else {
+              d[slot_of(4 * g) * 4] = v[u].x; d[slot_of(4 * g + 1) * 4] = v[u].y; d[slot_of(4 * g + 2) * 4] = v[u].z; d[slot_of(4 * g + 3) * 4] = v[u].w;
+            }
           }
         }
       }
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
 #pragma unroll
         for (int u = 0; u < SU; u++) {
           const int e = base + u * kMapThreads;
-          if (e < total) { const int c = e / HW, px = e - c * HW; mapw[((size_t)(c >> 2) * HW + px) * 4 + (c & 3)] = v[u]; }
+          if (e < total) { const int c = e / HW, px = e - c * HW; mapw[(size_t)(c >> 2) * (plane_bytes >> 2) + slot_of(px) * 4 + (c & 3)] = v[u]; }
         }
       }
     }
@@ -416,15 +427,22 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
-static int map_nq(const RoiAlignParams& p, int* use_slab) {
-  const long long HW = (long long)p.lv[0].height * p.lv[0].width;
+// channel quads per workgroup, whether the per-wave output slab fits beside the image, and the row pitch of the image: W + 1 for an
+// even W (odd pitch: fewer LDS conflicts in the tap gather) whenever that costs neither the second quad nor the slab
+static int map_nq(const RoiAlignParams& p, int* use_slab, int* pitch) {
+  const int H = p.lv[0].height, W = p.lv[0].width;
   const int bins = p.pooled_h * p.pooled_w;
   const bool slab_ok = bins <= 64 && (p.channels & 3) == 0;
+  static const bool pad_on = [] { const char* e = getenv("DTC_RA_MAP_PITCH"); return !(e && e[0] == '0'); }();     // A/B: DTC_RA_MAP_PITCH=0
   for (int nq = 2; nq >= 1; nq--) {
     if ((p.channels % (4 * nq)) != 0 && nq > 1) continue;            // whole channel groups (a tail only with single quads)
     const long long slab = slab_ok ? (long long)kMapWaves * 4 * nq * bins * 4 : 0;
-    if (HW * 16 * nq + slab <= kMapLdsBytes) { *use_slab = slab_ok ? 1 : 0; return nq; }
-    if (HW * 16 * nq <= kMapLdsBytes) { *use_slab = 0; return nq; }
+    for (int with_slab = 1; with_slab >= 0; with_slab--) {
+      for (int padded = (pad_on && (W & 1) == 0) ? 1 : 0; padded >= 0; padded--) {
+        const long long image = (long long)H * (W + padded) * 16 * nq;
+        if (image + (with_slab ? slab : 0) <= kMapLdsBytes) { *use_slab = with_slab && slab_ok ? 1 : 0; *pitch = W + padded; return nq; }
+      }
+    }
   }
   return 0;
 }
@@ -434,15 +452,15 @@ bool roi_align_map_supported(const RoiAlignParams& p, int in_dtype, int out_dtyp
   if (!(p.roi_desc || p.roi_cols == 4)) return false;                // image-major order is known only for these callers
   if (p.lv[0].stride_c == 1 && p.channels > 1) return false;         // channels_last: the NHWC / LDS kernels
   if ((long long)p.n_rois * p.channels < 64 * 1024) return false;    // too little work to pay for staging whole maps
-  int slab;
-  if (map_nq(p, &slab) == 0) return false;
+  int slab, pitch;
+  if (map_nq(p, &slab, &pitch) == 0) return false;
   const bool f = in_dtype == DTC_F32, h = in_dtype == DTC_F16, b = in_dtype == DTC_BF16;
   return (f && (out_dtype == DTC_F32 || out_dtype == DTC_F16 || out_dtype == DTC_BF16)) ||
          (h && (out_dtype == DTC_F32 || out_dtype == DTC_F16)) || (b && (out_dtype == DTC_F32 || out_dtype == DTC_BF16));
 }
 
 template <typename TIn, typename TOut, int NQ>
-static int launch_map_nq(const RoiAlignParams& p, int use_slab, hipStream_t stream) {
+static int launch_map_nq(const RoiAlignParams& p, int use_slab, int pitch, hipStream_t stream) {
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(once, [] {
@@ -461,16 +479,16 @@ static int launch_map_nq(const RoiAlignParams& p, int use_slab, hipStream_t stre
   if (seg_len < 8 * kMapWaves) seg_len = 8 * kMapWaves;
   seg_len = ceil_div(seg_len, kMapWaves) * kMapWaves;
   n_seg = ceil_div(p.n_rois, seg_len);
-  const size_t lds = (size_t)p.lv[0].height * p.lv[0].width * 16 * NQ + (use_slab ? (size_t)kMapWaves * 4 * NQ * bins * 4 : 0);
+  const size_t lds = (size_t)p.lv[0].height * pitch * 16 * NQ + (use_slab ? (size_t)kMapWaves * 4 * NQ * bins * 4 : 0);
   if (p.prep) {
     hipLaunchKernelGGL(map_prep_kernel, dim3((unsigned)ceil_div(p.n_rois, 4)), dim3(256), 0, stream, p,
-                       reinterpret_cast<MapPrepRoi*>(const_cast<void*>(p.prep)), roi_align_get_exact() ? 0 : 1);
+                       reinterpret_cast<MapPrepRoi*>(const_cast<void*>(p.prep)), roi_align_get_exact() ? 0 : 1, pitch);
     DTC_CHECK_LAUNCH();
     hipLaunchKernelGGL((roi_align_fwd_map<TIn, TOut, NQ, true>), dim3((unsigned)(ncg * n_seg)), dim3(kMapThreads), lds, stream, p,
-                       seg_len, use_slab);
+                       seg_len, use_slab, pitch);
   } else {
     hipLaunchKernelGGL((roi_align_fwd_map<TIn, TOut, NQ, false>), dim3((unsigned)(ncg * n_seg)), dim3(kMapThreads), lds, stream, p,
-                       seg_len, use_slab);
+                       seg_len, use_slab, pitch);
   }
   DTC_CHECK_LAUNCH();
   return DTC_OK;
@@ -479,9 +497,10 @@ static int launch_map_nq(const RoiAlignParams& p, int use_slab, hipStream_t stre
 template <typename TIn, typename TOut>
 static int launch_map_t(const RoiAlignParams& p, hipStream_t stream) {
   int use_slab = 0;
-  const int nq = map_nq(p, &use_slab);
-  if (nq == 2) return launch_map_nq<TIn, TOut, 2>(p, use_slab, stream);
-  if (nq == 1) return launch_map_nq<TIn, TOut, 1>(p, use_slab, stream);
+  int pitch = 0;
+  const int nq = map_nq(p, &use_slab, &pitch);
+  if (nq == 2) return launch_map_nq<TIn, TOut, 2>(p, use_slab, pitch, stream);
+  if (nq == 1) return launch_map_nq<TIn, TOut, 1>(p, use_slab, pitch, stream);
   return DTC_EUNSUPPORTED;
 }
 
