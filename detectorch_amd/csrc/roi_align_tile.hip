@@ -46,7 +46,9 @@ constexpr int kTileHdrBytes = kTileMaxK * (kTileRoiBytes + kTileGroupBytes) + 16
 // (512- and 1024-thread shapes -- K = 10 / 20 -- were built and measured in round 2: bit-exact, slower (0.42 / 0.54 ms against
 // 0.37), and spilling; removed in round 3, `git show 1687f14:detectorch_amd/csrc/roi_align_tile.hip`.)
 template <int NT> struct TileShape;
-template <> struct TileShape<256> { static constexpr int kUnits = 8, kWaves = 3, kLdsKB = 52; };
+template <> struct TileShape<256> { static constexpr int kUnits = 8, kWaves = 3, kLdsKB = 52, kWaves16 = 4, kLds16KB = 38; };
+// (16-bit maps: the LDS image is 16-bit, half the size -- 38 KB and <= 128 VGPRs put FOUR workgroups on a CU: cfg5 NCHW launch
+//  0.495 -> 0.448 ms; 36 KB does not hold the slab + a 20 KB image, 44 KB is three workgroups again)
 
 struct TileRoi {                        // 48 bytes
   int lvl, b, x0, x1, y0, y1, r, valid;   // window in feature pixels of its level, inclusive
@@ -67,14 +69,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base) {
   // raw buffer, no bounds clamp (num_records = 2^32 - 1); word 3 = DATA_FORMAT 32 (the gfx9 raw-buffer encoding)
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000);
 }
+// Piece4<T>::ld: four pixels of one channel as float32.  16-bit maps: Piece4<T>::raw keeps the four 16-bit values as loaded (two
+// dwords) -- the LDS image of a 16-bit map stays 16-bit (half the commit and tap bytes) and the taps are widened where they are
+// multiplied (mul_pair16: the same float32 values).
 template <typename TIn> struct Piece4;
 template <> struct Piece4<float> {
+  typedef float4 Raw;
+  static __device__ __forceinline__ Raw raw(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { return ld(r, voff, soff); }
   static __device__ __forceinline__ float4 ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
   }
 };
 template <> struct Piece4<__half> {
+  typedef u32x2 Raw;
+  static __device__ __forceinline__ Raw raw(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0); }
   static __device__ __forceinline__ float4 ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     const uint32_t x = v.x, y = v.y;
@@ -83,6 +92,8 @@ template <> struct Piece4<__half> {
   }
 };
 template <> struct Piece4<bf16_t> {
+  typedef u32x2 Raw;
+  static __device__ __forceinline__ Raw raw(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0); }
   static __device__ __forceinline__ float4 ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return bf16x4_to_f32(make_uint2(v.x, v.y));
@@ -107,7 +118,21 @@ struct TileTrace {};
 #define TT_MARK(i) ((void)0)
 #endif
 
-// LDS slot (16-byte units: one pixel x 4 channels) of window pixel px inside one quad image: one pad slot every 8 pixels
+// element type / slot size of the LDS image: float32 maps -> float32, 16 bytes per (pixel, 4 channels); 16-bit maps -> the raw 16-bit
+// values, 8 bytes per slot (tap = ds_read_b64; simulated on the bench RoIs, tools/r04/lds_taps4.py b64: 5.2 LDS cycles per tap read
+// against 9.6 for ds_read_b128 on a float32 image)
+template <typename TIn> struct TileLds { typedef float T; static constexpr int kSlot = 16, kShift = 4; };
+template <> struct TileLds<__half> { typedef uint16_t T; static constexpr int kSlot = 8, kShift = 3; };
+template <> struct TileLds<bf16_t> { typedef uint16_t T; static constexpr int kSlot = 8, kShift = 3; };
+
+#ifndef TILE_BF16_WAVES
+#define TILE_BF16_WAVES 4
+#endif
+template <typename TIn, int NT> struct TileBounds { static constexpr int kWaves = TileShape<NT>::kWaves; };
+template <int NT> struct TileBounds<__half, NT> { static constexpr int kWaves = TileShape<NT>::kWaves16; };
+template <int NT> struct TileBounds<bf16_t, NT> { static constexpr int kWaves = TILE_BF16_WAVES; };
+
+// LDS slot (one pixel x 4 channels) of window pixel px inside one quad image: one pad slot every 8 pixels
 __device__ __forceinline__ int tile_phys(int px) { return px + (px >> 3); }
 
 // Everything a lane needs to pool ITS (RoI, bin) from the LDS image, formed once per cluster.
@@ -149,10 +174,13 @@ struct TileGeom {            // one cluster, all uniform
 // pass p leaves for global memory as contiguous 16-byte stores while pass p+1 is being committed.
 template <typename TIn, typename TOut, int NT>
 __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_feat_level& L, const TIn* fbase, int c0, int nc,
-                                            int bins, float* slab, float* win, const TileRoi* troi, const TileGeom& g,
+                                            int bins, float* slab, typename TileLds<TIn>::T* win, const TileRoi* troi, const TileGeom& g,
                                             const TileItem& it, int rl, int bin, TileTrace& tt) {
   constexpr int NW = NT / 64;
   constexpr int U = TileShape<NT>::kUnits;
+  typedef typename TileLds<TIn>::T TL;
+  constexpr bool L16 = sizeof(TL) == 2;
+  constexpr int SB = TileLds<TIn>::kSlot;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, cl = (lane >> 4) & 3;
   const int npos = g.npos, ngx = g.ngx, plane = g.plane, nq_pass = g.nq_pass;
   const int nchunk = (npos + 15) >> 4;
@@ -162,7 +190,7 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
   const bool vec = g.mode != kStageScalar;
   uint32_t uoff[U];     // byte offset of the unit's piece (row, 4 pixels, channel 4q + cl) from the pass base plane; bits 30-31:
                         // how many pixels the piece was shifted left to stay inside its row (kStageVecUnaligned)
-  int ulds[U];          // float index of (first pixel of the piece, channel cl) in the LDS image
+  int ulds[U];          // element index of (first pixel of the piece, channel cl) in the LDS image
   // every pass is full: nq_pass divides the number of quads (caller), so nu = KC * nq_pass units carry data; the remaining
   // register slots DUPLICATE unit 0 (same bytes to the same LDS words) -- issue / commit are branch-free straight-line code,
   // all loads of a pass leave back to back.
@@ -186,30 +214,45 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
   }
   const __amdgpu_buffer_rsrc_t srd = make_srd(fbase);
   const uint32_t pass_bytes = (uint32_t)(L.stride_c * (int64_t)sizeof(TIn));       // per channel
-  float4 v[U];
+  typename Piece4<TIn>::Raw v[U];
   auto issue = [&](int cs) {      // vec only: every staged channel exists (nc % 4 == 0)
     const uint32_t soff = (uint32_t)cs * pass_bytes;
     if (g.mode == kStageVec) {
 #pragma unroll
-      for (int u = 0; u < U; u++) v[u] = Piece4<TIn>::ld(srd, uoff[u], soff);
+      for (int u = 0; u < U; u++) v[u] = Piece4<TIn>::raw(srd, uoff[u], soff);
     } else {
 #pragma unroll
-      for (int u = 0; u < U; u++) v[u] = Piece4<TIn>::ld(srd, uoff[u] & 0x3fffffffu, soff);
+      for (int u = 0; u < U; u++) v[u] = Piece4<TIn>::raw(srd, uoff[u] & 0x3fffffffu, soff);
     }
   };
   auto commit = [&]() {
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      float4 w = v[u];
-      if (g.mode == kStageVecUnaligned) {     // shifted piece: pixel k of the piece is component k + shift of the load
-        const uint32_t sft = uoff[u] >> 30;
-        w.x = sft == 0 ? w.x : sft == 1 ? w.y : sft == 2 ? w.z : w.w;
-        w.y = sft == 0 ? w.y : sft == 1 ? w.z : w.w;
-        w.z = sft == 0 ? w.z : w.w;             // components past the row end hold a copy of its last pixel: never sampled
+      if constexpr (L16) {
+        uint32_t w0 = v[u].x & 0xffffu, w1 = v[u].x >> 16, w2 = v[u].y & 0xffffu, w3 = v[u].y >> 16;
+        if (g.mode == kStageVecUnaligned) {
+          const uint32_t sft = uoff[u] >> 30;
+          w0 = sft == 0 ? w0 : sft == 1 ? w1 : sft == 2 ? w2 : w3;
+          w1 = sft == 0 ? w1 : sft == 1 ? w2 : w3;
+          w2 = sft == 0 ? w2 : w3;
+        }
+        TL* d = win + ulds[u];
+        d[0] = (TL)w0; d[4] = (TL)w1; d[8] = (TL)w2; d[12] = (TL)w3;
+      } else {
+        float4 w = v[u];
+        if (g.mode == kStageVecUnaligned) {     // shifted piece: pixel k of the piece is component k + shift of the load
+          const uint32_t sft = uoff[u] >> 30;
+          w.x = sft == 0 ? w.x : sft == 1 ? w.y : sft == 2 ? w.z : w.w;
+          w.y = sft == 0 ? w.y : sft == 1 ? w.z : w.w;
+          w.z = sft == 0 ? w.z : w.w;             // components past the row end hold a copy of its last pixel: never sampled
+        }
+        TL* d = win + ulds[u];
+        d[0] = w.x; d[4] = w.y; d[8] = w.z; d[12] = w.w;
       }
-      float* d = win + ulds[u];
-      d[0] = w.x; d[4] = w.y; d[8] = w.z; d[12] = w.w;
     }
+  };
+  auto lds_val = [&](const TIn& x) -> TL {          // what the LDS image holds of a map element
+    if constexpr (L16) return *reinterpret_cast<const uint16_t*>(&x); else return to_f32<TIn>(x);
   };
   // Strided columns, misaligned bases or a channel tail (channels_last maps, C % 4 != 0, maps narrower than 4): no register
   // pipeline, each piece is four clamped scalar loads written straight to LDS.  Correct for any strides; not a fast path.
@@ -227,11 +270,11 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
         const int gx = pos - row * ngx;
         const int rem = L.width - 1 - (g.x0a + 4 * gx);             // >= 0: a piece starts inside the map
         const TIn* s = base + (int64_t)(g.y0 + row) * L.stride_h + (int64_t)(g.x0a + 4 * gx) * L.stride_w;
-        float* d = win + q * plane * 4 + ((4 * pos + (pos >> 1)) << 2) + cl;
-        d[0] = to_f32<TIn>(s[0]);
-        d[4] = to_f32<TIn>(s[(int64_t)min(1, rem) * L.stride_w]);
-        d[8] = to_f32<TIn>(s[(int64_t)min(2, rem) * L.stride_w]);
-        d[12] = to_f32<TIn>(s[(int64_t)min(3, rem) * L.stride_w]);
+        TL* d = win + q * plane * 4 + ((4 * pos + (pos >> 1)) << 2) + cl;
+        d[0] = lds_val(s[0]);
+        d[4] = lds_val(s[(int64_t)min(1, rem) * L.stride_w]);
+        d[8] = lds_val(s[(int64_t)min(2, rem) * L.stride_w]);
+        d[12] = lds_val(s[(int64_t)min(3, rem) * L.stride_w]);
       }
     }
   };
@@ -279,24 +322,45 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
 #pragma unroll 1
       for (int q = 0; q < nq_cur; q++) {
         // uniform quad offset, opaque to the optimiser: otherwise every tap address becomes its own induction variable
-        const char* wq = reinterpret_cast<const char*>(win) + uni(q * plane * 16);
+        const char* wq = reinterpret_cast<const char*>(win) + uni(q * plane * SB);
         // two channels per instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE results, twice the fp32 rate of the scalar forms)
         f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
         // reference order: for iy { for ix { acc += w1*v1 + w2*v2 + w3*v3 + w4*v4 } }   (roi_align_cpu_loop.cpp:203-214)
 #pragma unroll
         for (int iy = 0; iy < 2; iy++) {
-          f32x4 t[2][4];
+          if constexpr (L16) {
+            u32x2 t[2][4];
 #pragma unroll
-          for (int ix = 0; ix < 2; ix++)
+            for (int ix = 0; ix < 2; ix++)
 #pragma unroll
-            for (int k = 0; k < 4; k++)                                       // 8 ds_read_b128 in flight per sample row
-              t[ix][k] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(wq + it.a[iy][ix][k], 16));
+              for (int k = 0; k < 4; k++)                                     // 8 ds_read_b64 in flight per sample row
+                t[ix][k] = *reinterpret_cast<const u32x2*>(__builtin_assume_aligned(wq + it.a[iy][ix][k], 8));
 #pragma unroll
-          for (int ix = 0; ix < 2; ix++) {
-            const float w1 = it.yh[iy] * it.xh[ix], w2 = it.yh[iy] * it.xl[ix];               // roi_align_cpu_loop.cpp:95
-            const float w3 = it.yl[iy] * it.xh[ix], w4 = it.yl[iy] * it.xl[ix];
-            a01 += w1 * t[ix][0].lo + w2 * t[ix][1].lo + w3 * t[ix][2].lo + w4 * t[ix][3].lo;    // :208-211
-            a23 += w1 * t[ix][0].hi + w2 * t[ix][1].hi + w3 * t[ix][2].hi + w4 * t[ix][3].hi;
+            for (int ix = 0; ix < 2; ix++) {
+              const float w1 = it.yh[iy] * it.xh[ix], w2 = it.yh[iy] * it.xl[ix];             // roi_align_cpu_loop.cpp:95
+              const float w3 = it.yl[iy] * it.xh[ix], w4 = it.yl[iy] * it.xl[ix];
+              f32x2 s01 = mul_pair16<TIn>(t[ix][0].x, w1) + mul_pair16<TIn>(t[ix][1].x, w2);    // :208-211, channels 0-1
+              s01 = s01 + mul_pair16<TIn>(t[ix][2].x, w3);
+              s01 = s01 + mul_pair16<TIn>(t[ix][3].x, w4);
+              f32x2 s23 = mul_pair16<TIn>(t[ix][0].y, w1) + mul_pair16<TIn>(t[ix][1].y, w2);    // channels 2-3
+              s23 = s23 + mul_pair16<TIn>(t[ix][2].y, w3);
+              s23 = s23 + mul_pair16<TIn>(t[ix][3].y, w4);
+              a01 = a01 + s01; a23 = a23 + s23;
+            }
+          } else {
+            f32x4 t[2][4];
+#pragma unroll
+            for (int ix = 0; ix < 2; ix++)
+#pragma unroll
+              for (int k = 0; k < 4; k++)                                     // 8 ds_read_b128 in flight per sample row
+                t[ix][k] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(wq + it.a[iy][ix][k], 16));
+#pragma unroll
+            for (int ix = 0; ix < 2; ix++) {
+              const float w1 = it.yh[iy] * it.xh[ix], w2 = it.yh[iy] * it.xl[ix];             // roi_align_cpu_loop.cpp:95
+              const float w3 = it.yl[iy] * it.xh[ix], w4 = it.yl[iy] * it.xl[ix];
+              a01 += w1 * t[ix][0].lo + w2 * t[ix][1].lo + w3 * t[ix][2].lo + w4 * t[ix][3].lo;    // :208-211
+              a23 += w1 * t[ix][0].hi + w2 * t[ix][1].hi + w3 * t[ix][2].hi + w4 * t[ix][3].hi;
+            }
           }
           __builtin_amdgcn_sched_barrier(0);      // keep the two sample rows apart: 32, not 64, tap registers live
         }
@@ -328,7 +392,7 @@ __device__ __forceinline__ int tile_work_item(int b, int n, int reverse) {
 }
 
 template <typename TIn, typename TOut, int NT>
-__global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct, int reverse) {
+__global__ __launch_bounds__(NT, (TileBounds<TIn, NT>::kWaves)) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct, int reverse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileRoi* troi = reinterpret_cast<TileRoi*>(smem);
   TileGroup* tgrp = reinterpret_cast<TileGroup*>(smem + kTileMaxK * kTileRoiBytes);
@@ -336,7 +400,9 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
   // [header][slab: K RoIs x 4 nq_cap channels x bins float32, fixed][image: nq quads x plane slots x 16 B]
   const int slab_bytes = kgroup * p.pooled_h * p.pooled_w * 16 * nq_cap;
   float* slab = reinterpret_cast<float*>(smem + kTileHdrBytes);
-  float* win = reinterpret_cast<float*>(smem + kTileHdrBytes + slab_bytes);
+  typedef typename TileLds<TIn>::T TL;
+  constexpr int SB = TileLds<TIn>::kSlot;
+  TL* win = reinterpret_cast<TL*>(smem + kTileHdrBytes + slab_bytes);
   const int win_bytes = lds_bytes - kTileHdrBytes - slab_bytes;
   constexpr int NW = NT / 64;
   constexpr int kMaxPos = TileShape<NT>::kUnits * NW * 16;                  // 16-byte pieces the register pipeline can carry per quad
@@ -400,7 +466,7 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
       else if (a_lvl < 0) g.kind = kGrpZero;
       else {
         const int ngx0 = (a_x1 >> 2) - (a_x0 >> 2) + 1, th0 = a_y1 - a_y0 + 1, npos0 = th0 * ngx0;
-        if (npos0 > kMaxPos || (4 * npos0 + (npos0 >> 1) + 1) * 16 > win_bytes || bins > NT) {
+        if (npos0 > kMaxPos || (4 * npos0 + (npos0 >> 1) + 1) * SB > win_bytes || bins > NT) {
           g.kind = kGrpGather;
         } else {
           g.kind = kGrpPool;
@@ -415,7 +481,7 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
             const int n_x0 = bc(t.x0, js), n_x1 = bc(t.x1, js), n_y0 = bc(t.y0, js), n_y1 = bc(t.y1, js);
             const int ux0 = min(g.x0, n_x0), ux1 = max(g.x1, n_x1), uy0 = min(g.y0, n_y0), uy1 = max(g.y1, n_y1);
             const int ungx = (ux1 >> 2) - (ux0 >> 2) + 1, uth = uy1 - uy0 + 1, unpos = uth * ungx;
-            if (unpos > kMaxPos || (4 * unpos + (unpos >> 1) + 1) * 16 > win_bytes) break;
+            if (unpos > kMaxPos || (4 * unpos + (unpos >> 1) + 1) * SB > win_bytes) break;
             const long long n_px = (long long)(n_y1 - n_y0 + 1) * (n_x1 - n_x0 + 1);
             const long long u_px = (long long)uth * (ux1 - ux0 + 1);
             if (u_px * 100 > (sum_px + n_px) * merge_pct) break;
@@ -491,7 +557,7 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
                      (reinterpret_cast<uintptr_t>(L.data) & 3) == 0;
     g.mode = !lin ? kStageScalar : al16 ? kStageVec : al4 ? kStageVecUnaligned : kStageScalar;
     const int KC = ceil_div((g.npos + 15) >> 4, NW);
-    g.nq_pass = max(1, min(min(win_bytes / (g.plane * 16), TileShape<NT>::kUnits / KC), min(ceil_div(nc, 4), nq_cap)));
+    g.nq_pass = max(1, min(min(win_bytes / (g.plane * SB), TileShape<NT>::kUnits / KC), min(ceil_div(nc, 4), nq_cap)));
     while (ceil_div(nc, 4) % g.nq_pass) g.nq_pass--;        // every pass full: no partial-pass code in the staging pipeline
     // ---- the lane's item -------------------------------------------------------------------------------------------
     const int n_it = count * bins;
@@ -514,8 +580,9 @@ __global__ __launch_bounds__(NT, TileShape<NT>::kWaves) void roi_align_fwd_tile(
     for (int iy = 0; iy < 2; iy++)
 #pragma unroll
       for (int ix = 0; ix < 2; ix++) {
-        int t0 = tile_phys(ylo[iy] + xlo[ix]) << 4, t1 = tile_phys(ylo[iy] + xhi[ix]) << 4;
-        int t2 = tile_phys(yhi[iy] + xlo[ix]) << 4, t3 = tile_phys(yhi[iy] + xhi[ix]) << 4;
+        constexpr int SS = TileLds<TIn>::kShift;
+        int t0 = tile_phys(ylo[iy] + xlo[ix]) << SS, t1 = tile_phys(ylo[iy] + xhi[ix]) << SS;
+        int t2 = tile_phys(yhi[iy] + xlo[ix]) << SS, t3 = tile_phys(yhi[iy] + xhi[ix]) << SS;
         asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));   // one finished VGPR per tap: do not re-derive in the loop
         it.a[iy][ix][0] = t0; it.a[iy][ix][1] = t1; it.a[iy][ix][2] = t2; it.a[iy][ix][3] = t3;
       }
@@ -545,6 +612,7 @@ namespace dtc {
 struct TileConfig {
   int nt = 256;        // threads per workgroup
   int lds_kb = 0;      // LDS per workgroup (0: TileShape<NT>::kLdsKB)
+  int lds16_kb = 0;    // ... for 16-bit maps (their LDS image is half the size)
   int k = 0;           // RoIs per workgroup (0: threads / bins)
   int ch_block = 0;    // channels per workgroup (0: chosen per launch)
   int merge_pct = 250; // a cluster may stage at most this % of the pixels its members would stage separately
@@ -552,10 +620,11 @@ struct TileConfig {
   int reverse = 1;     // walk an XCD's slice of the visiting order back to front (heaviest workgroups first)
   int cb_major = 1;    // an XCD walks its groups once per channel block
 };
-static const TileConfig& tile_config() {   // A/B knobs (DTC_RA_TILE_CHBLOCK, DTC_RA_TILE_CBMAJOR), resolved ONCE (thread-safe static initialisation)
+static const TileConfig& tile_config() {   // A/B knobs (DTC_RA_TILE_CHBLOCK, DTC_RA_TILE_CBMAJOR, DTC_RA_TILE_LDS16_KB), resolved ONCE (thread-safe static initialisation)
   static const TileConfig cfg = [] {
     TileConfig c;
     if (const char* e = getenv("DTC_RA_TILE_CBMAJOR")) c.cb_major = atoi(e) != 0;
+    if (const char* e = getenv("DTC_RA_TILE_LDS16_KB")) { const int v = atoi(e); if (v >= 36 && v <= 156) c.lds16_kb = v; }
     if (const char* e = getenv("DTC_RA_TILE_CHBLOCK")) { const int v = atoi(e); if (v >= 4 && (v & 3) == 0) c.ch_block = v; }
     return c;
   }();
@@ -570,7 +639,7 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   K = K < 1 ? 1 : (K > kTileMaxK ? kTileMaxK : K);
   if (K * bins > NT) K = NT / bins;
   if (K < 1) return DTC_EUNSUPPORTED;
-  const int lds_b = (cfg.lds_kb ? cfg.lds_kb : TileShape<NT>::kLdsKB) * 1024;
+  const int lds_b = (sizeof(TIn) == 2 ? (cfg.lds16_kb ? cfg.lds16_kb : TileShape<NT>::kLds16KB) : cfg.lds_kb ? cfg.lds_kb : TileShape<NT>::kLdsKB) * 1024;
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(once, [] {

@@ -301,7 +301,7 @@ print("ok")
 @pytest.mark.parametrize("env", ["DTC_ROIALIGN_TILE=0", "DTC_ROIALIGN_GENERAL=1", "DTC_ROIALIGN_TILE=0 DTC_RA_NO_CTS64=1",
                                  "DTC_ROIALIGN_MAP=0",
                                  "DTC_ROIALIGN_NO_NHWC_DIRECT=1", "DTC_RA_TILE_CHBLOCK=128", "DTC_RA_TILE_CHBLOCK=32",
-                                 "DTC_RA_TILE_CBMAJOR=0", "DTC_RA_NO_XCD=1", "DTC_RA_MAP_PREP=0", "DTC_RA_MAP_PITCH=0"])
+                                 "DTC_RA_TILE_CBMAJOR=0", "DTC_RA_NO_XCD=1", "DTC_RA_MAP_PREP=0", "DTC_RA_MAP_PITCH=0", "DTC_RA_TILE_LDS16_KB=52"])
 def test_kernel_variants_bit_exact_in_child_process(hip, oracle, env):
     """Every RoIAlign kernel that stays in the library -- the cluster-stationary default in its three workgroup shapes, the
     RoI-stationary LDS kernel with its stager options, the channels_last direct kernel, the per-output gather kernel -- does

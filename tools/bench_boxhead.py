@@ -15,12 +15,13 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--fp16", action="store_true")
+    ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--mask", action="store_true", help="time the 14x14 mask-head launch instead")
     ap.add_argument("--channels-last", action="store_true", help="NHWC feature maps (same logical shape)")
     ap.add_argument("--top-n", type=int, default=1000, help="RoIs per image after collect (cfg5: 2000)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
-    fdt = torch.float16 if a.fp16 else torch.float32
+    fdt = torch.float16 if a.fp16 else torch.bfloat16 if a.bf16 else torch.float32
     path = FpnRegionPath(a.batch, dev, feat_dtype=fdt, collect_top_n=a.top_n)
     path.bind(*synthetic_batch(a.batch, dev, seed=3000, feat_dtype=fdt, top_n=a.top_n, channels_last=a.channels_last))
     path.step(use_graph=False)
