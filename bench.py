@@ -502,11 +502,17 @@ def main():
                          "l1_fills": l1_fills,
                          "note": ("HBM traffic of this launch == its algorithmic bytes (every feature byte is staged once: map-stationary "
                                   "kernel); what bounds it is the adaptive-grid gather from LDS -- ~5 samples x 4 taps per bin and channel, "
-                                  "formed with the reference's unfused multiply-adds -- i.e. VALU issue, not HBM (DESIGN 3.6)") if wl == "cfg2" else
+                                  "formed with the reference's unfused multiply-adds -- i.e. LDS reads and VALU issue, not HBM (DESIGN 3.6)") if wl == "cfg2" else
+                                 ("direct-gather kernel (roi_align_nhwc16.hip, DESIGN 3.1): every tap is a 16-byte load per lane straight from L1 / L2, "
+                                  "fabric traffic ~ the compulsory bytes; recorded counters of the 8000-RoI fp16 launch "
+                                  "(profiles/r04_z_nhwc16_boxhead_counters.json, not measured in this run): 91 % L1 hits, texture data path (TD) "
+                                  "83 % busy, VALU 59 % -- the floor of this formulation is the 64 B/clk/CU load-return path plus the reference's "
+                                  "unfused multiply-adds, not HBM") if a.channels_last else
                                  "two stacked floors (DESIGN 3.1, profiles/r04_a_*): the fabric -- the launch requests 2.3 x its algorithmic bytes "
                                  "as L1 line fills, about half of which miss the XCD's L2 (fills that hit L2 run at ~22 TB/s, fills served by "
                                  "the Infinity Cache / HBM at 6-8 TB/s) -- and the CU side: with the maps cache-resident and 81 % L2 hits the "
-                                 "same kernel still takes 0.30-0.35 ms (issue-bound: LDS transposition, tap gather, address arithmetic)"},
+                                 "same kernel still takes 0.30-0.35 ms (LDS pipe 77 % busy: tap gather with bank conflicts, transposing commit; "
+                                 "profiles/r04_k_cluster_kernel_sq_counters.json)"},
             "consistency": {"timed_region_s": round(dt, 4), "one_stream_ms_per_step": None if one_stream_ms is None else round(one_stream_ms, 4),
                             "gathered_equals_local": gathered_ok,
                             "gathered_equals_recomputed": recomputed_ok,
