@@ -19,9 +19,6 @@
 
 namespace dtc {
 
-#ifndef N16_MIN_WG
-#define N16_MIN_WG 1
-#endif
 constexpr int kN16Threads = 256;
 constexpr int kN16MaxG = 8;
 constexpr int kN16SlabBytes = 25 * 1024 + 512;   // output slab budget per workgroup (4 RoIs x 64 channels x 49 bins x 2 B = 25 088)
@@ -82,7 +79,8 @@ __device__ __forceinline__ void n16_pool_bin(const N16Tab& y0e, const N16Tab& y1
 
 // CB: channels per workgroup (64, or 32 when a 64-channel slab of one RoI exceeds the budget: 14 x 14 bins with float32 output)
 template <typename TIn, typename TOut, int CB>
-__global__ __launch_bounds__(kN16Threads, N16_MIN_WG) void roi_align_fwd_nhwc16(RoiAlignParams p, const char* base0, int G) {
+// (98 VGPRs: four workgroups per CU; bounding it to five -- 96 VGPRs -- measured no difference and spilled the bf16 variants)
+__global__ __launch_bounds__(kN16Threads) void roi_align_fwd_nhwc16(RoiAlignParams p, const char* base0, int G) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int bins = p.pooled_h * p.pooled_w;
   const int ny = 2 * p.pooled_h, ne = 2 * (p.pooled_h + p.pooled_w);
