@@ -55,12 +55,14 @@ template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return
 // nearest even (NaN stays NaN).  No arithmetic happens in bf16: the kernels accumulate in float32.
 struct bf16_t { uint16_t bits; };
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return __uint_as_float((uint32_t)v.bits << 16); }
+// round to nearest even on the bit pattern, NaN -> truncated payload | quiet bit (what torch's .to(bfloat16) does).  gfx950 has the
+// instruction: v_cvt_pk_bf16_f32 equals the six-instruction bit arithmetic it replaces on ALL 2^32 inputs (NaNs, denormals and
+// infinities included; exhaustive check on the GPU: tools/micro/bf16_cvt_check.hip)
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) {
-  uint32_t u = __float_as_uint(v);
+  uint32_t u;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(u) : "v"(v));
   bf16_t r;
-  if ((u & 0x7fffffffu) > 0x7f800000u) { r.bits = (uint16_t)((u >> 16) | 0x0040u); return r; }   // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  r.bits = (uint16_t)(u >> 16);
+  r.bits = (uint16_t)u;
   return r;
 }
 __device__ __forceinline__ float4 bf16x4_to_f32(uint2 r) {
