@@ -2,9 +2,9 @@
 # SQ counters of the pipelined channels_last kernel (box-head launch of the bench inputs)
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r04k; mkdir -p $O
+O=gpurun_out/${OUT_TAG:-r04k}; mkdir -p $O
 rocprofv3 -L 2>/dev/null | grep -oE "\bSQ_[A-Z_0-9]+\b" | sort -u | tr '\n' ' ' > $O/sq_counter_names.txt
-BOX="python tools/bench_boxhead.py --iters 4"
+BOX="python tools/bench_boxhead.py --iters 4 ${BOX_ARGS:-}"
 i=0
 for G in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
          "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD" \
