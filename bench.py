@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--sustain-seconds", type=float, default=1.0, help="extra untimed-by-contract run of at least this long, reported under `consistency`")
     ap.add_argument("--inflight", type=int, default=2, help="steps in flight: consecutive steps (independent batches) are issued round-robin on this many HIP streams, so the latency-bound kernels of one step overlap the RoIAlign launches of another")
+    ap.add_argument("--side-steps", type=int, default=100, help="timed steps of each short leg of the OTHER BASELINE configurations (cfg5 channels_last, cfg5 NCHW, cfg2) reported under `other_workloads` of a default cfg3 line at one GPU; 0 = none")
     ap.add_argument("--split", type=int, default=1, help="sub-batches run on separate HIP streams inside one hipGraph (cfg3/cfg5)")
     return ap.parse_args()
 
@@ -131,7 +132,7 @@ def _cpu_image_parallel(jobs, budget_s=90.0, max_procs=None):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def cpu_baseline(workload, inputs, path, n_images, c4_pooled, max_procs=None):
+def cpu_baseline(workload, inputs, path, n_images, c4_pooled, max_procs=None, image_parallel=True):
     """Run the CPU checker on the first n_images images of the SAME inputs the timed GPU steps used, (1) time it -- single
     thread: the reference is single-threaded (OpenMP pragma commented out at lib/cppcuda/roi_align_cpu.cpp:136-137; Cython
     loops are serial) -- and (2) compare every intermediate with what the GPU path produced for those images
@@ -196,11 +197,113 @@ def cpu_baseline(workload, inputs, path, n_images, c4_pooled, max_procs=None):
                                       "level ids, pooled features, detections%s) == CPU checker, bit-exact%s"
                                       % (", mask-branch features, binarised crops" if workload != "cfg2" else "",
                                          "" if workload != "cfg5" else " (fp16 pooled features: rel 1e-3)")}}
-    if jobs is not None:
+    if jobs is not None and image_parallel:
         try:   # informational; the single-core figure above is the contract
             out["image_parallel"] = _cpu_image_parallel(jobs, max_procs=max_procs)
         except Exception as e:
             out["image_parallel"] = {"error": repr(e)}
+    return out
+
+
+def recorded_traffic(wl, batch, channels_last, fp16, k_ms):
+    """HBM-side bytes per launch of the box-head RoIAlign of this workload: the committed rocprofv3 --pmc TCC_EA0_* passes
+    (profiles/roialign_traffic.json, profiles/README.md), returned only while the hash of the running kernel source matches the one
+    the counters were collected on.  -> (traffic bytes | None, source string | None, l1 fill record | None)."""
+    traffic, traffic_src, l1_fills = None, None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "roialign_traffic.json")))
+        key = "%s_b%d_%s_%s" % (wl, batch, "nhwc" if channels_last else "nchw", "f16" if fp16 else "f32")
+        if key in tj:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from kernel_hash import kernel_sha16
+            stamped = tj.get(key + "_detail", {}).get("kernel_sha16")
+            running = kernel_sha16(wl, channels_last=channels_last)
+            if stamped == running and "l1_fill_requests" in tj.get(key + "_detail", {}):
+                # the vector L1s' line fills of this launch (TCP -> TCC read requests x 128 B, same counter run)
+                nreq = int(tj[key + "_detail"]["l1_fill_requests"])
+                l1_fills = {"requests_per_launch": nreq, "bytes_per_launch": nreq * 128,
+                            "rate_TBps": round(nreq * 128 / (k_ms * 1e-3) / 1e12, 2),
+                            "l2_read_hit_fraction": tj[key + "_detail"].get("l2_read_hit_fraction"),
+                            "fill_latency_cycles": tj[key + "_detail"].get("l1_fill_latency_cycles"),
+                            # RECORDED microbenchmark results (a pure-load kernel, tools/micro/l1_fill_ceiling.hip), NOT measured in this run
+                            "recorded_pure_load_TBps": tj.get("pure_load_ceilings_recorded"),
+                            "source": tj[key + "_detail"].get("l1_fill_source")}
+            if stamped == running:               # the counters were collected on THIS kernel source
+                traffic, traffic_src = tj[key], "profiles/roialign_traffic.json[%s] (rocprofv3 --pmc TCC_EA0_* passes, tools/collect_profiles.sh; not measured in this run; kernel source hash %s matches)" % (key, stamped)
+            else:
+                traffic_src = "profiles/roialign_traffic.json[%s] is stale: collected on kernel source %s, running %s" % (key, stamped, running)
+    except Exception:
+        pass
+    return traffic, traffic_src, l1_fills
+
+
+def side_leg(wl, channels_last, a, dev, steps, cpu_images):
+    """A SHORT leg of another BASELINE configuration in the same process, after the contract line's timed region (VERDICT r04 item 2:
+    cfg5 / cfg2 figures were builder-run only).  Same construction as the headline: two bound input sets, hipGraph replay, two steps in
+    flight, `steps` timed steps between synchronisations; then the one-stream step, HIP-event samples of the box-head RoIAlign launch,
+    and the parity check of the first `cpu_images` images of the timed tensors against the CPU checker (a mismatch aborts the run)."""
+    from detectorch_amd import hip
+    from detectorch_amd.pipeline import C4RegionPath, FpnRegionPath, StepPipeline, synthetic_batch, synthetic_c4_batch
+    fp16 = wl == "cfg5"
+    fdt = torch.float16 if fp16 else torch.float32
+    top_n = 2000 if wl == "cfg5" else 1000
+    paths, inputs = [], []
+    for s in range(2):
+        seed = {"cfg3": 3000, "cfg5": 5000, "cfg2": 2000}[wl] + 500 * s
+        if wl == "cfg2":
+            p = C4RegionPath(a.batch, dev, pooled=a.c4_pooled, feat_dtype=fdt)
+            inp = synthetic_c4_batch(a.batch, dev, seed=seed, feat_dtype=fdt)
+        else:
+            p = FpnRegionPath(a.batch, dev, feat_dtype=fdt, collect_top_n=top_n, max_out=a.max_out)
+            inp = synthetic_batch(a.batch, dev, seed=seed, top_n=top_n, feat_dtype=fdt, channels_last=channels_last, max_out=a.max_out)
+        p.bind(*inp)
+        paths.append(p)
+        inputs.append(inp)
+
+    def run(n_inflight, n):
+        pipe = StepPipeline(paths, dev, n_inflight=n_inflight)
+        for _ in range(4):
+            pipe.step(use_graph=not a.eager)
+        pipe.synchronize()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            pipe.step(use_graph=not a.eager)
+        pipe.synchronize()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n
+
+    t2 = run(2, steps)
+    t1 = run(1, max(20, steps // 2))
+    iters = a.kernel_iters
+    for _ in range(5):
+        for p in paths:
+            p._roi_align_box()
+    e0 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    e1 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    for i in range(iters):
+        e0[i].record()
+        paths[i % 2]._roi_align_box()
+        e1[i].record()
+    torch.cuda.synchronize(dev)
+    k_all = [e0[i].elapsed_time(e1[i]) for i in range(iters)]
+    k_ms = float(np.mean(k_all))
+    alg = paths[0].box_roialign_bytes()
+    traffic, traffic_src, _ = recorded_traffic(wl, a.batch, channels_last, fp16, k_ms)
+    paths[0].step(use_graph=not a.eager)
+    torch.cuda.synchronize(dev)
+    cb = cpu_baseline(wl, inputs[0], paths[0], cpu_images, a.c4_pooled, image_parallel=False)
+    out = {"workload_id": wl, "feature_layout": "NHWC" if channels_last else "NCHW", "dtype": "f16" if fp16 else "f32",
+           "rois_per_image": top_n, "images_per_gpu_per_step": a.batch, "steps": steps,
+           "value": round(a.batch / t2, 2), "unit": "images/sec", "ms_per_step": round(t2 * 1e3, 4),
+           "one_stream_ms_per_step": round(t1 * 1e3, 4),
+           "roofline": {"bound": "hbm", "kernel": "roi_align (box head)", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(k_ms, 4),
+                        "launch_ms_min_median_max": [round(float(np.min(k_all)), 4), round(float(np.median(k_all)), 4), round(float(np.max(k_all)), 4)]},
+           "parity_checked": cb["parity_checked"], "cpu_baseline_images_per_sec": cb["value"]}
+    del paths, inputs
+    torch.cuda.empty_cache()
     return out
 
 
@@ -209,14 +312,8 @@ def harder_set_launch(path, feats, top_n, dev, iters):
     bin 1.3 px): the generator of tools/bench_roialign.py --sort -- log-uniform sides 16-600 px, FPN level by area, visited in
     (image, level, row band, x) order -- on the feature maps of the timed steps.  Same kernel, same launch shape."""
     from detectorch_amd import hip, synth
-    B = path.B
-    rs = synth.rng(3, 0)
-    rois = np.concatenate([np.hstack([np.full((top_n, 1), b, np.float32), synth.make_rois(rs, top_n)]) for b in range(B)])
-    area = (rois[:, 3] - rois[:, 1] + 1) * (rois[:, 4] - rois[:, 2] + 1)
-    lvn = (np.clip(np.floor(4 + np.log2(np.sqrt(area) / 224 + 1e-6)), 2, 5) - 2).astype(np.int32)
-    yc, xc = (rois[:, 2] + rois[:, 4]) * 0.5, (rois[:, 1] + rois[:, 3]) * 0.5
-    band = (yc / (4.0 * 2.0 ** lvn * 32)).astype(np.int32)
-    order = torch.from_numpy(np.lexsort((xc, band, lvn, rois[:, 0])).astype(np.int32)).to(dev)
+    rois, lvn, order_np = synth.harder_roi_set(path.B, top_n)
+    order = torch.from_numpy(order_np).to(dev)
     lv, rois_t = torch.from_numpy(lvn).to(dev), torch.from_numpy(rois).to(dev)
     out = torch.empty((rois.shape[0], feats[0].shape[1], path.box_p, path.box_p), dtype=path.box_feats.dtype, device=dev)
     run = lambda: hip.roi_align_forward(feats, synth.FPN_ROI_SCALES, rois_t, path.box_p, path.box_p, 2, roi_levels=lv, out=out, roi_order=order)
@@ -436,32 +533,7 @@ def main():
         if not recomputed_ok:
             raise SystemExit("detections gathered from another rank differ from their recomputation on rank 0")
 
-    traffic, traffic_src, l1_fills = None, None, None
-    try:   # HBM-side bytes per launch of the same kernel/config: rocprofv3 --pmc passes, committed (profiles/README.md)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "roialign_traffic.json")))
-        key = "%s_b%d_%s_%s" % (wl, a.batch, "nhwc" if a.channels_last else "nchw", "f16" if fp16 else "f32")
-        if key in tj:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            from kernel_hash import kernel_sha16
-            stamped = tj.get(key + "_detail", {}).get("kernel_sha16")
-            running = kernel_sha16(wl, channels_last=a.channels_last)
-            if stamped == running and "l1_fill_requests" in tj.get(key + "_detail", {}):
-                # the vector L1s' line fills of this launch (TCP -> TCC read requests x 128 B, same counter run) against the rate a
-                # kernel that ONLY loads reaches with this kernel's workgroup shape and load pattern (tools/micro/l1_fill_ceiling.hip)
-                nreq = int(tj[key + "_detail"]["l1_fill_requests"])
-                l1_fills = {"requests_per_launch": nreq, "bytes_per_launch": nreq * 128,
-                            "rate_TBps": round(nreq * 128 / (k_ms * 1e-3) / 1e12, 2),
-                            "l2_read_hit_fraction": tj[key + "_detail"].get("l2_read_hit_fraction"),
-                            "fill_latency_cycles": tj[key + "_detail"].get("l1_fill_latency_cycles"),
-                            # RECORDED microbenchmark results (a pure-load kernel, tools/micro/l1_fill_ceiling.hip), NOT measured in this run
-                            "recorded_pure_load_TBps": tj.get("pure_load_ceilings_recorded"),
-                            "source": tj[key + "_detail"].get("l1_fill_source")}
-            if stamped == running:               # the counters were collected on THIS kernel source
-                traffic, traffic_src = tj[key], "profiles/roialign_traffic.json[%s] (rocprofv3 --pmc TCC_EA0_* passes, tools/collect_profiles.sh; not measured in this run; kernel source hash %s matches)" % (key, stamped)
-            else:
-                traffic_src = "profiles/roialign_traffic.json[%s] is stale: collected on kernel source %s, running %s" % (key, stamped, running)
-    except Exception:
-        pass
+    traffic, traffic_src, l1_fills = recorded_traffic(wl, a.batch, a.channels_last, fp16, k_ms)
 
     if rank == 0:
         n_img = a.batch * a.steps * world
@@ -528,6 +600,16 @@ def main():
             # rank 0 only; at N > 1 a shorter sample (the other ranks wait at the final barrier meanwhile)
             out["cpu_baseline"] = cpu_baseline(wl, inputs[0], p0, a.cpu_images if world == 1 else min(a.cpu_images, 2), a.c4_pooled,
                                                max_procs=a.cpu_procs)
+        if (world == 1 and a.side_steps > 0 and wl == "cfg3" and not a.channels_last and not a.fp16 and not a.no_cpu_baseline
+                and not isinstance(p0, OverlappedRegionPath)):
+            # BASELINE configs[4] (both layouts) and configs[1], short legs, AFTER everything the headline reports was measured
+            del pipe
+            paths.clear(); inputs.clear()
+            torch.cuda.empty_cache()
+            out["other_workloads"] = {
+                "cfg5_nhwc": side_leg("cfg5", True, a, dev, a.side_steps, 2),
+                "cfg5_nchw": side_leg("cfg5", False, a, dev, a.side_steps, 2),
+                "cfg2": side_leg("cfg2", False, a, dev, max(20, a.side_steps // 2), 2)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

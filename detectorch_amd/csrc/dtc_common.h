@@ -14,6 +14,11 @@
 #include "../../include/detectorch_hip.h"
 
 #define DTC_WAVE 64
+// One target: the inline assembly below (v_cvt_pk_bf16_f32, v_fma_mix_f32 with an SGPR operand, global_load_lds_dwordx4) exists on
+// gfx950 only.  Any other --offload-arch stops HERE with a readable message instead of somewhere inside the assembler.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libdetectorch_hip is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
 #define DTC_API extern "C" __attribute__((visibility("default")))
 
 #define DTC_CHECK_LAUNCH()                                 \

@@ -64,6 +64,21 @@ def make_rois(rs, R, im_h=IM_H, im_w=IM_W, min_side=16.0, max_side=600.0):
     return b.astype(np.float32)
 
 
+def harder_roi_set(batch, top_n, seed_config=3, seed_index=0):
+    """The HARDER RoI population of the bench line's `roofline.harder_set` and of the real-shape parity tests: `top_n` boxes per
+    image with log-uniform sides 16-600 px (a trained RPN looks like that; the bench's own RPN-on-noise proposals sit 94 % on P2),
+    FPN level by area (the heuristic of multilevel_rois.py:19-39 in float64), visited in (image, level, 32-row band, x) order.
+    Returns (rois5 [B*top_n,5] float32, level ids [B*top_n] int32 in 0..3, visiting order [B*top_n] int32)."""
+    rs = rng(seed_config, seed_index)
+    rois = np.concatenate([np.hstack([np.full((top_n, 1), b, np.float32), make_rois(rs, top_n)]) for b in range(batch)])
+    area = (rois[:, 3] - rois[:, 1] + 1) * (rois[:, 4] - rois[:, 2] + 1)
+    lvn = (np.clip(np.floor(4 + np.log2(np.sqrt(area) / 224 + 1e-6)), 2, 5) - 2).astype(np.int32)
+    yc, xc = (rois[:, 2] + rois[:, 4]) * 0.5, (rois[:, 1] + rois[:, 3]) * 0.5
+    band = (yc / (4.0 * 2.0 ** lvn * 32)).astype(np.int32)
+    order = np.lexsort((xc, band, lvn, rois[:, 0])).astype(np.int32)
+    return rois, lvn, order
+
+
 def make_rpn_outputs(rs, A, H, W, tie_free=True):
     """(rpn_cls_prob [1,A,H,W] = sigmoid(N(-2,2)), rpn_bbox_pred [1,4A,H,W] = N(0,0.2))."""
     x = rs.standard_normal((1, A, H, W)) * 2.0 - 2.0

@@ -64,14 +64,84 @@ def test_mask_rcnn_fpn_eval_flow(channels_last):
     assert sum(len(s) for s in segms) == D and all(r['size'] == [200, 280] for s in segms for r in s)
 
 
-def test_faster_rcnn_c4_flow():
+def test_faster_rcnn_c4_flow(oracle):
+    """eval_faster.ipynb flow (detector.py:240-248): shapes, AND the proposals the model returns == the oracle's GenerateProposals on
+    the model's OWN RPN-head outputs (captured with a forward hook), AND the pooled features that reach the res5 head == the oracle's
+    RoIAlign of those proposals on the model's own res4 map."""
     from detectorch_amd.model.detector import detector
     torch.manual_seed(0)
     model = detector(arch='resnet50', use_rpn_head=True).cuda()
+    seen = {}
+    h1 = model.rpn.register_forward_hook(lambda m, i, o: seen.__setitem__("rpn", (o[0].clone(), o[1].clone())))
+    h2 = model.conv_head.register_forward_hook(lambda m, i, o: seen.__setitem__("pooled", i[0].clone()))
     image = torch.randn(1, 3, 256, 320, device="cuda")
     cls_score, bbox_pred, rois, feats = model(image, scaling_factor=1.0)
+    h1.remove(); h2.remove()
     assert rois.shape[1] == 4 and cls_score.shape[0] == rois.shape[0] and bbox_pred.shape[1] == 324
     assert tuple(feats.shape) == (1, 1024, 16, 20)
+    score, deltas = seen["rpn"]
+    prob = oracle.rpn_sigmoid(score[0].cpu().numpy()) if model.fuse_rpn_sigmoid else score[0].cpu().numpy()
+    want, _ = oracle.generate_proposals(prob, deltas[0].cpu().numpy(), oracle.generate_anchors(stride=16), 16.0, 256, 320, 6000, 1000, 0.7)
+    assert want.shape[0] > 50 and np.array_equal(rois.cpu().numpy(), want)
+    rois5 = np.hstack([np.zeros((want.shape[0], 1), np.float32), want])
+    ref = oracle.roi_align_forward(feats.cpu().numpy(), rois5, 14, 14, 0.0625, 0)
+    assert np.array_equal(seen["pooled"].cpu().numpy(), ref)
+
+
+def test_fast_rcnn_c4_precomputed_rois_branch(oracle):
+    """eval_fast.ipynb:227 (BASELINE configs[0]'s plumbing): detector without an RPN head, proposals handed in by the caller as a
+    [1,R,4] tensor (the notebook's `rois.unsqueeze(0)`-style batch) -- detector.py:240-248 `rois=` branch.  The pooled features
+    that reach the head are the oracle's RoIAlign of THOSE rows in THAT order; the returned rois are the caller's."""
+    from detectorch_amd import synth
+    from detectorch_amd.model.detector import detector
+    torch.manual_seed(0)
+    model = detector(arch='resnet50', use_rpn_head=False).cuda()
+    seen = {}
+    hk = model.conv_head.register_forward_hook(lambda m, i, o: seen.__setitem__("pooled", i[0].clone()))
+    image = torch.randn(1, 3, 256, 320, device="cuda")
+    boxes = synth.make_rois(synth.rng(9, 1), 37, im_h=256, im_w=320, min_side=12.0, max_side=200.0)
+    cls_score, bbox_pred, rois, feats = model(image, rois=torch.from_numpy(boxes).cuda().unsqueeze(0), scaling_factor=1.0)
+    hk.remove()
+    assert tuple(cls_score.shape) == (37, 81) and tuple(bbox_pred.shape) == (37, 324)
+    ref = oracle.roi_align_forward(feats.cpu().numpy(), np.hstack([np.zeros((37, 1), np.float32), boxes]), 14, 14, 0.0625, 0)
+    assert np.array_equal(seen["pooled"].cpu().numpy(), ref)
+    rows = rois[0] if rois.dim() == 3 else rois
+    assert np.array_equal(rows.cpu().numpy()[:, -4:], boxes)
+
+
+def test_fast_rcnn_fpn_precomputed_per_level_rois_and_restore_index(oracle):
+    """eval_fast_FPN.ipynb:238: FPN detector without an RPN head; the caller distributes its proposals over the levels
+    (add_multilevel_rois_for_test) and passes the per-level lists + `roi_original_idx` (detector.py:260-270).  Row i of the pooled
+    features that reach fc6 must be the oracle's RoIAlign of ORIGINAL proposal i on ITS level's map -- a wrong level order or a
+    wrong restore index fails this -- and the returned rois are the original proposals in the original order."""
+    from detectorch_amd import synth
+    from detectorch_amd.model.detector import detector
+    from detectorch_amd.utils.multilevel_rois import add_multilevel_rois_for_test
+    torch.manual_seed(0)
+    model = detector(arch='resnet50', conv_body_layers=['conv1', 'bn1', 'relu', 'maxpool', 'layer1', 'layer2', 'layer3', 'layer4'],
+                     conv_head_layers='two_layer_mlp', fpn_layers=['layer1', 'layer2', 'layer3', 'layer4'], fpn_extra_lvl=True,
+                     roi_height=7, roi_width=7, roi_spatial_scale=[0.25, 0.125, 0.0625, 0.03125], roi_sampling_ratio=2,
+                     use_rpn_head=False).cuda()
+    seen = {}
+    hk = model.conv_head.register_forward_hook(lambda m, i, o: seen.__setitem__("pooled", i[0].clone()))
+    image = torch.randn(1, 3, 320, 448, device="cuda")
+    boxes = synth.make_rois(synth.rng(9, 2), 83, im_h=320, im_w=448, min_side=10.0, max_side=440.0)
+    blobs = add_multilevel_rois_for_test({'rois': boxes}, 'rois')
+    keys = ['rois_fpn2', 'rois_fpn3', 'rois_fpn4', 'rois_fpn5']
+    assert all(len(blobs[k]) > 0 for k in keys)                       # every level is populated: a level swap cannot hide
+    per_level = [torch.from_numpy(np.ascontiguousarray(blobs[k])).cuda() for k in keys]
+    restore = torch.from_numpy(blobs['rois_idx_restore_int32']).cuda().long()
+    assert not np.array_equal(blobs['rois_idx_restore_int32'], np.arange(83))
+    cls_score, bbox_pred, rois, feats = model(image, rois=per_level, scaling_factor=1.0, roi_original_idx=restore)
+    hk.remove()
+    assert tuple(cls_score.shape) == (83, 81) and np.array_equal(rois.cpu().numpy(), boxes)
+    lv = oracle.map_rois_to_fpn_levels(boxes, 2, 5) - 2
+    ref = np.zeros((83, 256, 7, 7), np.float32)
+    rois5 = np.hstack([np.zeros((83, 1), np.float32), boxes])
+    for l in range(4):
+        m = lv == l
+        ref[m] = oracle.roi_align_forward(feats[l].cpu().numpy(), rois5[m], 7, 7, [0.25, 0.125, 0.0625, 0.03125][l], 2)
+    assert np.array_equal(seen["pooled"].cpu().numpy().reshape(83, 256, 7, 7), ref)
 
 
 def _boost(model, k=60.0):

@@ -57,24 +57,27 @@ def test_cfg5_shape_2000_proposals_fp16_features(oracle):
     assert np.array_equal(path.dets[0, :D].cpu().numpy(), ref["dets"][:D])
 
 
-def test_cfg5_real_shape_batch8_c256_fp16(oracle):
-    """BASELINE cfg5 at its REAL shape (round-2 VERDICT: only C = 8, B = 1 was tested): B = 8 images x 2000 RoIs, C = 256, fp16
-    feature maps, hipGraph replay.  That is the 16 000-RoI launch of the cluster-stationary kernel with 128-channel blocks
-    (roi_align_tile.hip: ngrp * ceil(C / 128) >= 6144).  Image 0 against the oracle chain on the up-cast maps: proposals,
-    levels and detections exact, fp16 pooled features to rel 1e-3; and the same launch with FLOAT32 output bit-equal."""
+@pytest.mark.parametrize("layout", ["nhwc", "nchw"])
+def test_cfg5_real_shape_batch8_c256_fp16(oracle, layout):
+    """BASELINE cfg5 at its REAL shape: B = 8 images x 2000 RoIs, C = 256, fp16 feature maps, hipGraph replay -- in BOTH layouts
+    bench.py times: channels_last (cfg5's default since round 4: roi_align_fwd_nhwc16<__half,__half,64>, bins of four RoIs dealt over
+    a workgroup) and NCHW (the cluster kernel with the 16-bit LDS image).  Image 0 against the oracle chain on the up-cast maps
+    (proposals, levels, detections exact); the float32 output of the SAME 16 000 descriptors bit-equal to the oracle for EVERY image,
+    and the fp16 output of the fused path == that, rounded once."""
     import chain
-    from detectorch_amd import hip
+    from detectorch_amd import hip, synth
     from detectorch_amd.pipeline import FpnRegionPath, synthetic_batch
     dev = torch.device("cuda", 0)
     B, C, T = 8, 256, 2000
     path = FpnRegionPath(B, dev, channels=C, collect_top_n=T, feat_dtype=torch.float16)
-    inputs = synthetic_batch(B, dev, seed=5000, channels=C, top_n=T, feat_dtype=torch.float16)
+    inputs = synthetic_batch(B, dev, seed=5000, channels=C, top_n=T, feat_dtype=torch.float16, channels_last=layout == "nhwc")
     path.bind(*inputs)
     path.step(use_graph=True)
     path.step(use_graph=True)
     torch.cuda.synchronize()
     rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, sf, im_size = inputs
-    host = lambda t: t.float().cpu().numpy()
+    assert feats[0].is_contiguous(memory_format=torch.channels_last) == (layout == "nhwc")
+    host = lambda t: np.ascontiguousarray(t.float().cpu().numpy())
     b = 0
     ref = chain.fpn_hot_path([host(c[b]) for c in rpn_cls], [host(d[b]) for d in rpn_bbox], [host(f[b:b + 1]) for f in feats],
                              host(cls_score[b]), host(bbox_pred[b]), host(masks[b * path.max_out:(b + 1) * path.max_out]),
@@ -86,12 +89,19 @@ def test_cfg5_real_shape_batch8_c256_fp16(oracle):
     assert np.allclose(path.box_feats[:n].float().cpu().numpy(), ref["box_feats"], rtol=1e-3, atol=1e-3)
     D = min(int(path.det_count[b]), path.max_out)
     assert np.array_equal(path.dets[b, :D].cpu().numpy(), ref["dets"][:D])
-    # fp32 output of the SAME 16 000-descriptor launch (fp16 maps, fp32 accumulate, no final rounding): bit-equal
+    # fp32 output of the SAME 16 000-descriptor launch (fp16 maps, fp32 accumulate, no final rounding): bit-equal, every image
     out32 = torch.empty((B * T, C, 7, 7), dtype=torch.float32, device=dev)
     hip.check(hip.lib().dtc_roi_align_forward_packed(path.feat_lv, 4, C, hip.DTC_F16, path.roi_desc.data_ptr(), B * T, 7, 7, 2,
                                                      out32.data_ptr(), hip.DTC_F32, hip.stream_ptr(dev)), "packed fp16->fp32")
     torch.cuda.synchronize()
     assert np.array_equal(out32[:n].cpu().numpy(), ref["box_feats"])
+    maps = [host(f) for f in feats]
+    rois5, lv = path.rois5.reshape(-1, 5).cpu().numpy(), path.roi_levels.reshape(-1).cpu().numpy()
+    got = out32.cpu().numpy()
+    for l in range(4):
+        m = lv == l
+        assert np.array_equal(got[m], oracle.roi_align_forward(maps[l], np.ascontiguousarray(rois5[m]), 7, 7, synth.FPN_ROI_SCALES[l], 2))
+    assert not got[lv < 0].any()                                      # padding rows: zeros
     assert torch.equal(out32.to(torch.float16), path.box_feats)       # every image: the fp16 output is that, rounded once
 
 

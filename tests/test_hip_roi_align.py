@@ -570,3 +570,101 @@ def test_nhwc_lds_image_sizes_in_child_process(hip, oracle, env):
         e[k] = v
     r = subprocess.run([sys.executable, "-c", _NHWC_CHILD % root], env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, env + "\n" + r.stdout[-1500:] + r.stderr[-3000:]
+
+
+# ---- REAL-SHAPE dispatches of the round-4 / round-5 kernels: B = 8 images, C = 256, 8000 / 16 000 RoIs ----------
+def _oracle_levels(oracle, maps, rois5, lv, ph, sr=2):
+    """Oracle RoIAlign of a multi-level launch: `maps` float32 numpy [B,C,H,W] per level, level id -1 (padding row) -> zeros."""
+    ref = np.zeros((rois5.shape[0], maps[0].shape[1], ph, ph), np.float32)
+    for l in range(len(maps)):
+        m = lv == l
+        if m.any():
+            ref[m] = oracle.roi_align_forward(maps[l], np.ascontiguousarray(rois5[m]), ph, ph, synth.FPN_ROI_SCALES[l], sr)
+    return ref
+
+
+def _bench_population(B, T, C, dev, feat_dtype, channels_last, seed):
+    """The bench's OWN RoIs: the fused path (GenerateProposals -> NMS -> collect / distribute) on the bench's synthetic batch; returns
+    the path (rois5, level ids, visiting order, packed descriptors, box_feats of the real launch) and the feature maps."""
+    from detectorch_amd.pipeline import FpnRegionPath, synthetic_batch
+    path = FpnRegionPath(B, dev, channels=C, collect_top_n=T, feat_dtype=feat_dtype, max_out=104)
+    inputs = synthetic_batch(B, dev, seed=seed, channels=C, top_n=T, feat_dtype=feat_dtype, channels_last=channels_last, max_out=104)
+    path.bind(*inputs)
+    path.step(use_graph=False)
+    torch.cuda.synchronize()
+    return path, inputs[2]
+
+
+@pytest.mark.parametrize("population", ["bench", "harder"])
+@pytest.mark.parametrize("layout", ["nhwc", "nchw"])
+def test_real_shape_box_head_fp32_c256_8000_rois(hip, oracle, layout, population):
+    """The float32 box head at the bench's real shape -- 8 images x 1000 RoIs, C = 256, 7 x 7 bins, sampling ratio 2 -- on
+    channels_last maps (roi_align_fwd_nhwc16<float>, G = 2) AND NCHW maps (the cluster kernel), on BOTH RoI populations bench.py times:
+    the path's own proposals (seed 3000) and the log-uniform 16-600 px `harder_set`.  All 8000 RoIs bit-equal to the oracle."""
+    dev = torch.device("cuda", 0)
+    B, T, C = 8, 1000, 256
+    path, feats = _bench_population(B, T, C, dev, torch.float32, layout == "nhwc", 3000)
+    maps = [f.float().cpu().numpy() for f in feats]          # .cpu().numpy() of a channels_last tensor keeps the logical NCHW index order
+    maps = [np.ascontiguousarray(m) for m in maps]
+    if population == "bench":
+        rois5 = path.rois5.reshape(-1, 5).cpu().numpy()
+        lv = path.roi_levels.reshape(-1).cpu().numpy()
+        got = path.box_feats.cpu().numpy()                   # the launch of the fused path itself (packed descriptors, restored order)
+        assert int(path.n_rois.min()) > 900
+    else:
+        rois5, lv, order = synth.harder_roi_set(B, T)
+        assert len(np.unique(lv)) == 4
+        got = hip.roi_align_forward(feats, synth.FPN_ROI_SCALES, cu(rois5), 7, 7, 2, roi_levels=cu(lv), roi_order=cu(order)).cpu().numpy()
+    ref = _oracle_levels(oracle, maps, rois5, lv, 7)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("layout", ["nhwc", "nchw"])
+@pytest.mark.parametrize("population", ["bench", "harder"])
+def test_real_shape_bf16_maps_and_output_c256_8000_rois(hip, oracle, layout, population):
+    """bf16 maps -> bf16 pooled features at the real shape (8 x 1000 RoIs, C = 256): float32 accumulation of the up-cast maps equals the
+    oracle bit for bit; the bf16 output (v_cvt_pk_bf16_f32 in the kernels' store path) equals torch's round-to-nearest-even of it."""
+    dev = torch.device("cuda", 0)
+    B, T, C = 8, 1000, 256
+    path, feats32 = _bench_population(B, T, C, dev, torch.float32, False, 3000)
+    feats = [f.to(torch.bfloat16) for f in feats32]
+    maps = [np.ascontiguousarray(f.float().cpu().numpy()) for f in feats]
+    if layout == "nhwc":
+        feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
+    if population == "bench":
+        rois5, lv, order = path.rois5.reshape(-1, 5), path.roi_levels.reshape(-1), path.roi_order.reshape(-1)
+        rois5_np, lv_np = rois5.cpu().numpy(), lv.cpu().numpy()
+    else:
+        rois5_np, lv_np, order_np = synth.harder_roi_set(B, T)
+        rois5, lv, order = cu(rois5_np), cu(lv_np), cu(order_np)
+    ref = _oracle_levels(oracle, maps, rois5_np, lv_np, 7)
+    out32 = hip.roi_align_forward(feats, synth.FPN_ROI_SCALES, rois5, 7, 7, 2, roi_levels=lv, roi_order=order)
+    assert np.array_equal(out32.cpu().numpy(), ref)
+    out16 = hip.roi_align_forward(feats, synth.FPN_ROI_SCALES, rois5, 7, 7, 2, roi_levels=lv, roi_order=order, out_dtype=torch.bfloat16)
+    assert torch.equal(out16.cpu(), torch.from_numpy(ref).to(torch.bfloat16))
+
+
+def test_bf16_output_rounding_special_values(hip, oracle):
+    """the bf16 store is an inline v_cvt_pk_bf16_f32.  Channels that are CONSTANT maps of special float32 values, pooled by
+    RoIs whose samples fall on pixel centres (weights exactly (1, 0, 0, 0), 4 v / 4 == v): ties to even in both directions, the largest
+    value below a tie, denormals, -0, values that round up into the next binade, NaN.  bf16 output == torch's .to(bfloat16) of the
+    oracle's float32 result (NaN compared as NaN)."""
+    bits = [0x3F808000, 0x3F818000, 0x3F807FFF, 0x3F808001, 0x3FFF8000, 0x3FFFFFFF, 0x00000001, 0x00008000, 0x00018000, 0x007FFFFF,
+            0x80000000, 0x80008000, 0xBF808000, 0x7E7F8000, 0x7E7FFFFF, 0x00800000, 0x7FC00001, 0x3F800000, 0x477FE000, 0x0000FFFF]
+    vals = np.array(bits, np.uint32).view(np.float32)
+    C, H, W = len(bits), 24, 24
+    f = np.broadcast_to(vals[None, :, None, None], (1, C, H, W)).astype(np.float32).copy()
+    # 7 x 7 bins over 14 px, sampling ratio 2: sample k of an axis sits at start + 0.5 + k -> integer coordinates for start = n + 0.5
+    rois5 = np.array([[0, 3.5, 2.5, 17.5, 16.5], [0, 1.5, 4.5, 15.5, 18.5]], np.float32)
+    ref = oracle.roi_align_forward(f, rois5, 7, 7, 1.0, 2)
+    same = ~np.isnan(vals) & (vals.view(np.uint32) != 0x80000000)      # (the accumulator starts at +0: 0 + (-0) = +0)
+    assert np.array_equal(ref[:, same].view(np.uint32), np.broadcast_to(vals[same].view(np.uint32)[None, :, None, None], (2, int(same.sum()), 7, 7)))
+    want = torch.from_numpy(ref).to(torch.bfloat16)
+    for layout in ("nchw", "nhwc"):
+        t = cu(f)
+        if layout == "nhwc":
+            t = t.contiguous(memory_format=torch.channels_last)
+        got = hip.roi_align_forward(t, 1.0, cu(rois5), 7, 7, 2, out_dtype=torch.bfloat16).cpu()
+        nan = torch.isnan(want)
+        assert torch.equal(torch.isnan(got), nan)
+        assert torch.equal(got.view(torch.int16)[~nan], want.view(torch.int16)[~nan])
