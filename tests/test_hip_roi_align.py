@@ -301,7 +301,7 @@ print("ok")
 @pytest.mark.parametrize("env", ["DTC_ROIALIGN_TILE=0", "DTC_ROIALIGN_GENERAL=1", "DTC_ROIALIGN_TILE=0 DTC_RA_NO_CTS64=1",
                                  "DTC_ROIALIGN_MAP=0",
                                  "DTC_ROIALIGN_NO_NHWC_DIRECT=1", "DTC_RA_TILE_CHBLOCK=128", "DTC_RA_TILE_CHBLOCK=32",
-                                 "DTC_RA_TILE_CBMAJOR=0", "DTC_RA_NO_XCD=1", "DTC_RA_MAP_PREP=0", "DTC_RA_MAP_PITCH=0", "DTC_RA_TILE_LDS16_KB=52"])
+                                 "DTC_RA_TILE_CBMAJOR=0", "DTC_RA_TILE2=0", "DTC_RA_NO_XCD=1", "DTC_RA_MAP_PREP=0", "DTC_RA_MAP_PITCH=0", "DTC_RA_TILE_LDS16_KB=52"])
 def test_kernel_variants_bit_exact_in_child_process(hip, oracle, env):
     """Every RoIAlign kernel that stays in the library -- the cluster-stationary default in its three workgroup shapes, the
     RoI-stationary LDS kernel with its stager options, the channels_last direct kernel, the per-output gather kernel -- does
@@ -668,3 +668,43 @@ def test_bf16_output_rounding_special_values(hip, oracle):
         nan = torch.isnan(want)
         assert torch.equal(torch.isnan(got), nan)
         assert torch.equal(got.view(torch.int16)[~nan], want.view(torch.int16)[~nan])
+
+
+@pytest.mark.parametrize("out_dtype", ["f32", "f16", "bf16"])
+def test_tile2_staging_paths(hip, oracle, out_dtype):
+    """The round-5 float32 cluster kernel (roi_align_fwd_tile2): every staging path against the oracle, bit-exact --
+    windows that need six units per thread (17-24 blocks of 4 x 4 pieces), a box over most of the coarsest map (both LDS images as
+    one, single-buffered), a box over the whole finest map (per-output gather), windows on the right / bottom edge of every level
+    (the duplicated last column / row that the clamped taps read; P5's 42 columns = unaligned pieces), clusters that merge and
+    clusters that cannot, on 7 x 7 and 14 x 14 bins, float32 / fp16 / bf16 output."""
+    rs = synth.rng(11, 5)
+    shapes = synth.fpn_level_shapes()[:4]
+    C = 16
+    feats = [synth.make_features(rs, (2, C, h, w)) - 0.25 for (h, w) in shapes]
+    W, H = 1344.0, 800.0
+    rows = []
+    for l, s in enumerate((4.0, 8.0, 16.0, 32.0)):
+        rows += [[l, 0, 0, W - 1, H - 1]]                                        # the whole map of the level
+        rows += [[l, W - 1 - 30 * s, H - 1 - 12 * s, W - 1, H - 1]]              # bottom-right corner: duplicate column AND row
+        rows += [[l, W - 1 - 20 * s, 3 * s, W + 40, 15 * s]]                     # hangs over the right edge
+        rows += [[l, 5 * s, H - 1 - 9 * s, 17 * s, H + 100]]                     # hangs over the bottom edge
+        rows += [[l, 2 * s, 2 * s, 2 * s + 35 * s, 2 * s + 20 * s]]              # 35 x 20 px window: 3 x 6 = 18 blocks -> six units
+        rows += [[l, 1 * s, 1 * s, 1 * s + 41 * s, 1 * s + 23.5 * s]]            # ~ 43 x 26: more than one image on 7 x 7 -> big path
+        for k in range(12):                                                      # neighbours that merge into clusters
+            rows += [[l, (10 + 3 * k) * s, 6 * s, (22 + 3 * k) * s, 17 * s]]
+    rows = np.array(rows, np.float32)
+    lv = rows[:, 0].astype(np.int32)
+    R = rows.shape[0]
+    rois5 = np.hstack([(np.arange(R) % 2).astype(np.float32)[:, None], rows[:, 1:]])
+    # clusters only form between consecutive RoIs of one image: visit image 0's rows, then image 1's
+    order = np.concatenate([np.arange(0, R, 2), np.arange(1, R, 2)]).astype(np.int32)
+    odt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[out_dtype]
+    for ph in (7, 14):
+        ref = _oracle_levels(oracle, feats, rois5, lv, ph)
+        for od in (None, order):
+            out = hip.roi_align_forward([cu(f) for f in feats], synth.FPN_ROI_SCALES, cu(rois5), ph, ph, 2, roi_levels=cu(lv),
+                                        roi_order=None if od is None else cu(od), out_dtype=odt)
+            if out_dtype == "f32":
+                assert np.array_equal(out.cpu().numpy(), ref), ph
+            else:
+                assert torch.equal(out.cpu(), torch.from_numpy(ref).to(odt)), ph

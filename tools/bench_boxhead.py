@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--mask", action="store_true", help="time the 14x14 mask-head launch instead")
     ap.add_argument("--channels-last", action="store_true", help="NHWC feature maps (same logical shape)")
     ap.add_argument("--top-n", type=int, default=1000, help="RoIs per image after collect (cfg5: 2000)")
+    ap.add_argument("--harder", action="store_true", help="the harder RoI population (synth.harder_roi_set) instead of the path's own proposals")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     fdt = torch.float16 if a.fp16 else torch.bfloat16 if a.bf16 else torch.float32
@@ -27,6 +28,13 @@ def main():
     path.step(use_graph=False)
     torch.cuda.synchronize()
     fn = path._roi_align_mask if a.mask else path._roi_align_box
+    if a.harder:
+        from detectorch_amd import hip, synth
+        rois, lvn, order = synth.harder_roi_set(a.batch, a.top_n)
+        rois_t, lv, od = (torch.from_numpy(x).to(dev) for x in (rois, lvn, order))
+        P = path.mask_p if a.mask else path.box_p
+        out = torch.empty((rois.shape[0], path.C, P, P), dtype=fdt, device=dev)
+        fn = lambda: hip.roi_align_forward(path.feats, synth.FPN_ROI_SCALES, rois_t, P, P, 2, roi_levels=lv, out=out, roi_order=od)
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
