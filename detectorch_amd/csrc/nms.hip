@@ -73,7 +73,7 @@ __device__ __forceinline__ float vmin(float a, float b) { float d; asm("v_min_f3
 constexpr int kMaskWaves = 4;  // a workgroup = 4 wavefronts = 4 consecutive column blocks of one row block
 
 __global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4* __restrict__ boxes,
-                                                                   const int32_t* __restrict__ counts, int n_stride,
+                                                                   const int32_t* __restrict__ counts, int n_stride, int n_cap,
                                                                    int ncb_stride, float thresh,
                                                                    uint64_t* __restrict__ mask,
                                                                    uint64_t* __restrict__ diag_t) {
@@ -84,7 +84,9 @@ __global__ __launch_bounds__(64 * kMaskWaves) void nms_mask_kernel(const float4*
   __shared__ float4 rbox_s[64];
   __shared__ float rarea_s[64];
   const int s = blockIdx.z;
-  const int n = counts ? min(counts[s], n_stride) : n_stride;
+  // n_cap: only the leading n_cap rows / columns of the segment (the first phase of a keep[:max_keep] call, see dtc_nms_sorted);
+  // a NEGATIVE count = a segment that needs nothing (n <= 0: no tile is enumerated)
+  const int n = min(counts ? min(counts[s], n_stride) : n_stride, n_cap);
   const int ncb = (n + 63) >> 6;
   const int ncg = (ncb + kMaskWaves - 1) / kMaskWaves;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -220,13 +222,15 @@ __device__ __forceinline__ void reduce_load(ReduceRegs& R, const uint64_t* __res
 
 __global__ __launch_bounds__(64) void nms_reduce_kernel(const uint64_t* __restrict__ mask,
                                                         const uint64_t* __restrict__ diag_t,
-                                                        const int32_t* __restrict__ counts, int n_stride,
+                                                        const int32_t* __restrict__ counts, int n_stride, int n_cap,
                                                         int ncb_stride, int max_keep, int32_t* __restrict__ keep,
-                                                        int keep_stride, int32_t* __restrict__ keep_count) {
+                                                        int keep_stride, int32_t* __restrict__ keep_count,
+                                                        int32_t* __restrict__ next_counts) {
   __shared__ uint64_t removed[256];            // one bit per box, up to 16384 boxes
   const int s = blockIdx.x, lane = threadIdx.x, rg = lane >> 4, cbl = lane & 15;
-  if (counts && counts[s] < 0) return;         // a segment somebody else has already reduced (det_candidates: <= 64 candidates)
-  const int n = counts ? min(counts[s], n_stride) : n_stride;
+  if (counts && counts[s] < 0) return;         // a segment that is already reduced (the first phase below finished it): keep / keep_count stay
+  const int n_full = counts ? min(counts[s], n_stride) : n_stride;
+  const int n = min(n_full, n_cap);
   const int ncb = (n + 63) >> 6;
   const uint64_t* M = mask + (size_t)s * n_stride * ncb_stride;
   const uint64_t* DT = diag_t + (size_t)s * n_stride;
@@ -286,7 +290,12 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const uint64_t* __restri
     }
     cur = nxt;
   }
-  if (lane == 0) keep_count[s] = kept;
+  if (lane == 0) {
+    keep_count[s] = kept;
+    // first phase of a keep[:max_keep] call: the segment is finished when max_keep boxes are kept (rows past the last kept one can
+    // not change the first max_keep survivors) or when it had no more than n_cap rows; otherwise the second phase redoes it in full
+    if (next_counts) next_counts[s] = (kept >= cap || n_full <= n_cap) ? -1 : n_full;
+  }
 }
 
 // The same walk with the segment's whole suppression matrix in LDS: for few, long segments (the RPN call: 40 segments of 1000
@@ -455,8 +464,9 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 DTC_API size_t dtc_nms_sorted_workspace_bytes(int n_seg, int n_stride) {
   const size_t ncb = (size_t)(n_stride + 63) / 64;
   // suppression matrix [n_seg][n_stride][ncb] + transposed diagonal tiles [n_seg][n_stride]
+  // + the per-segment counts the second phase of a keep[:max_keep] call runs on
   return dtc::align_up((size_t)n_seg * n_stride * ncb * sizeof(uint64_t), 256) +
-         dtc::align_up((size_t)n_seg * n_stride * sizeof(uint64_t), 256);
+         dtc::align_up((size_t)n_seg * n_stride * sizeof(uint64_t), 256) + dtc::align_up((size_t)n_seg * sizeof(int32_t), 256);
 }
 
 DTC_API int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg, int n_stride, float thresh,
@@ -473,23 +483,43 @@ DTC_API int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg,
   uint64_t* mask = reinterpret_cast<uint64_t*>(workspace);
   uint64_t* diag_t = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(workspace) +
                                                  dtc::align_up((size_t)n_seg * n_stride * ((n_stride + 63) / 64) * sizeof(uint64_t), 256));
-  // workgroups per segment: all tile groups when there are few segments (RPN: 40 x 64), a handful when there are many
-  // (detections: 640 class segments, mostly one tile each)
-  // (tile groups on or above the diagonal of a full segment: see the kernel)
-  const int ncg = (ncb + dtc::kMaskWaves - 1) / dtc::kMaskWaves;
-  int groups = 0;
-  for (int q = 0; q <= ncb / dtc::kMaskWaves; q++) {
-    const int rows = ncb - q * dtc::kMaskWaves < dtc::kMaskWaves ? ncb - q * dtc::kMaskWaves : dtc::kMaskWaves;
-    groups += (ncg - q) * (rows > 0 ? rows : 0);
+  int32_t* next_counts = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(diag_t) + dtc::align_up((size_t)n_seg * n_stride * sizeof(uint64_t), 256));
+  // tile groups on or above the diagonal of a segment of ncb_ column blocks (see the kernel)
+  auto upper_groups = [](int ncb_) {
+    const int ncg = (ncb_ + dtc::kMaskWaves - 1) / dtc::kMaskWaves;
+    int groups = 0;
+    for (int q = 0; q <= ncb_ / dtc::kMaskWaves; q++) {
+      const int rows = ncb_ - q * dtc::kMaskWaves < dtc::kMaskWaves ? ncb_ - q * dtc::kMaskWaves : dtc::kMaskWaves;
+      groups += (ncg - q) * (rows > 0 ? rows : 0);
+    }
+    return groups;
+  };
+  auto launch_mask = [&](const int32_t* cnts, int n_cap) {
+    // about 2000 workgroups per launch: every one of a few long segments' groups, ONE workgroup for each of many short segments
+    // (the 640 class segments of a detection batch hold ~10 candidates = one tile each)
+    const int groups = upper_groups(((n_cap < n_stride ? n_cap : n_stride) + 63) / 64);
+    int gx = 2048 / n_seg;
+    if (gx < 1) gx = 1;
+    if (gx > groups) gx = groups;
+    hipLaunchKernelGGL(dtc::nms_mask_kernel, dim3(gx, 1, n_seg), dim3(64 * dtc::kMaskWaves), 0, s,
+                       reinterpret_cast<const float4*>(boxes), cnts, n_stride, n_cap, ncb, thresh, mask, diag_t);
+  };
+  // keep[:max_keep] of a LONG segment (the C4 RPN call: 6000 sorted boxes, 1000 kept -- generate_proposals.py:114-117): the first
+  // max_keep survivors are decided by the leading rows alone (the 1000th kept box of the bench's C4 batches is row ~1100), so the
+  // first phase builds and walks only the leading n1 x n1 corner of the matrix (n1 = 2048: 528 of 4465 tiles, 2 of 6 column chunks
+  // per row block); a segment that has not reached max_keep by row n1 is redone in full by the second phase, every other segment
+  // is marked finished (count -1) and costs the second phase two empty workgroups.  Same keep lists either way.
+  const int n1 = ((2 * max_keep + 63) / 64 < 16 ? 16 : (2 * max_keep + 63) / 64) * 64;
+  const bool two_phase = max_keep > 0 && n_stride >= 2 * n1;
+  if (two_phase) {
+    launch_mask(counts, n1);
+    DTC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dtc::nms_reduce_kernel, dim3(n_seg), dim3(64), 0, s, mask, diag_t, counts, n_stride, n1, ncb, max_keep, keep,
+                       keep_stride, keep_count, next_counts);
+    DTC_CHECK_LAUNCH();
+    counts = next_counts;
   }
-  // about 2000 workgroups per launch: every one of a few long segments' groups, ONE workgroup for each of many short segments
-  // (the 640 class segments of a detection batch hold ~10 candidates = one tile each: 6 workgroups per segment were 3200
-  // launched to return at once)
-  int gx = 2048 / n_seg;
-  if (gx < 1) gx = 1;
-  if (gx > groups) gx = groups;
-  hipLaunchKernelGGL(dtc::nms_mask_kernel, dim3(gx, 1, n_seg), dim3(64 * dtc::kMaskWaves), 0, s,
-                     reinterpret_cast<const float4*>(boxes), counts, n_stride, ncb, thresh, mask, diag_t);
+  launch_mask(counts, n_stride);
   DTC_CHECK_LAUNCH();
   // few long segments whose matrix fits LDS (the RPN call): the LDS walk (see the kernel); else the one-wave walk
   const size_t lds_need = ((size_t)ncb * 64 * ncb + (size_t)ncb * 64) * sizeof(uint64_t);
@@ -500,8 +530,8 @@ DTC_API int dtc_nms_sorted(const float* boxes, const int32_t* counts, int n_seg,
     hipLaunchKernelGGL(dtc::nms_reduce_lds_kernel, dim3(n_seg), dim3(dtc::kReduceLdsThreads), lds_need, s, mask, diag_t, counts,
                        n_stride, ncb, max_keep, keep, keep_stride, keep_count);
   } else {
-    hipLaunchKernelGGL(dtc::nms_reduce_kernel, dim3(n_seg), dim3(64), 0, s, mask, diag_t, counts, n_stride, ncb, max_keep, keep,
-                       keep_stride, keep_count);
+    hipLaunchKernelGGL(dtc::nms_reduce_kernel, dim3(n_seg), dim3(64), 0, s, mask, diag_t, counts, n_stride, n_stride, ncb, max_keep, keep,
+                       keep_stride, keep_count, static_cast<int32_t*>(nullptr));
   }
   DTC_CHECK_LAUNCH();
   return DTC_OK;

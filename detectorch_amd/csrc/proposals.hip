@@ -13,8 +13,9 @@
 //                     of :64,72 is only an index formula.
 //   rpn_compact       elements above that bin -> 64-bit (score desc, canonical index asc) keys that are certainly selected;
 //                     elements inside it (a few dozen at most, unless the map is constant) -> candidate keys.
-//   rpn_sort_decode   one workgroup per segment: bitonic sort of selected + candidate keys in LDS (the first K are the
-//                     answer, ties broken by the canonical index), then per rank: anchor = f(index) from the A base anchors
+//   rpn_sort          one workgroup per segment: bitonic sort of selected + candidate keys in LDS (the first K are the
+//                     answer, ties broken by the canonical index);
+//   rpn_decode        256 ranks per workgroup: anchor = f(index) from the A base anchors
 //                     (never materialised, :124-149), decode (:165-214), clip (:216-238), filter (:151-163),
 //                     order-preserving compaction.  More candidates than the sort holds (constant / saturated maps): an
 //                     in-workgroup radix select over the candidate keys first.
@@ -52,6 +53,11 @@ struct RpnParams {
   uint32_t* counters;   // [S][2] : selected count, candidate count
   uint64_t* gt_keys;    // [S][k_stride]
   uint64_t* cand_keys;  // [B][ties_per_image]
+  uint64_t* sorted_keys;  // [S][k_stride]   keys of ranks [0, n_rank) in (score desc, index asc) order: rpn_sort -> rpn_decode
+  int32_t* n_rank;        // [S]
+  uint32_t* ticket;       // [S]             dynamic block index of rpn_decode (cleared with the histograms)
+  uint32_t* blk_cnt;      // [S][decode blocks]  (count << 1) | ready, cleared with the histograms
+  int dec_blocks;         // decode workgroups per segment
   float* out_boxes;     // [S][k_stride][4]
   float* out_scores;    // [S][k_stride]
   int32_t* out_counts;  // [S]
@@ -258,12 +264,11 @@ __device__ __forceinline__ void select_digit_asc(uint32_t* hist, int nbins, uint
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_decode_kernel(RpnParams p, int sort_cap) {
+__global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_kernel(RpnParams p, int sort_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
   __shared__ uint32_t sh[2];
   __shared__ __attribute__((aligned(16))) uint32_t hsel[2048];
-  __shared__ int wave_tot[kSortDecodeThreads / 64];
   __shared__ int running;
   const int seg = blockIdx.x;
   const int b = seg / p.n_levels, l = seg - b * p.n_levels;
@@ -328,55 +333,95 @@ __global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_decode_kernel(Rpn
   block_bitonic_sort<kSortDecodeThreads>(keys, np2);
   DTC_PT(3, seg, 2);
 
-  // ranks [0, K) in score order: decode, clip, filter, ordered compaction
+  // the first K keys are the answer: hand them to rpn_decode (a segment's 6000 ranks are decoded by 24 workgroups, not by this one)
+  const int n_rank = min(K, total);
+  uint64_t* sk = p.sorted_keys + (size_t)seg * p.k_stride;
+  for (int k = tid; k < n_rank; k += kSortDecodeThreads) sk[k] = keys[k];
+  if (tid == 0) p.n_rank[seg] = n_rank;
+  DTC_PT(3, seg, 3);
+}
+
+// ranks [0, K) in score order: decode, clip, filter, ORDERED compaction -- spread over the chip.  Round 4 measured the decode of a
+// C4 segment (6000 ranks, two correctly rounded exp each) at 70 us inside the one-workgroup sort kernel: 16 waves x ~1500
+// instructions on ONE CU.  Here a workgroup of 256 threads decodes 256 consecutive ranks; the boxes a filter removes (min-size /
+// centre-outside, generate_proposals.py:151-163) shift everything behind them, so the output slot of a rank needs the number of
+// surviving ranks before it: every workgroup publishes its survivor count and sums the counts of the blocks before it (at most 63:
+// one poll per lane).  Blocks are numbered by a TICKET taken at run time, so the blocks a workgroup waits for are always already
+// running, whatever order the hardware dispatches workgroups in.
+constexpr int kDecodeThreads = 256;
+__global__ __launch_bounds__(kDecodeThreads) void rpn_decode_kernel(RpnParams p) {
+  __shared__ int sh_blk, sh_base;
+  __shared__ int wave_tot[kDecodeThreads / 64];
+  const int seg = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = seg / p.n_levels, l = seg - b * p.n_levels;
+  const RpnLevelDev& L = p.lv[l];
+  if (tid == 0) sh_blk = (int)atomicAdd(&p.ticket[seg], 1u);
+  __syncthreads();
+  const int blk = sh_blk;
+  const int n_rank = p.n_rank[seg];
+  const uint64_t* sk = p.sorted_keys + (size_t)seg * p.k_stride;
   const float* sc = L.cls + (size_t)b * L.N;
   const float* dl = L.bbox + (size_t)b * L.N * 4;
   const int HW = L.H * L.W;
   float* ob = p.out_boxes + (size_t)seg * p.k_stride * 4;
   float* os = p.out_scores + (size_t)seg * p.k_stride;
-  if (tid == 0) running = 0;
-  __syncthreads();
-  const int n_rank = min(K, total);
-  for (int k0 = 0; k0 < n_rank; k0 += kSortDecodeThreads) {
-    const int k = k0 + tid;
-    bool ok = false;
-    float box[4] = {0.f, 0.f, 0.f, 0.f};
-    float s = 0.f;
-    if (k < n_rank) {
-      const uint32_t n = desc_key_index(keys[k]);
-      const int a = n % L.A, hw = n / L.A;
-      const int h = hw / L.W, w = hw - h * L.W;
-      s = L.logit ? desc_key_score(keys[k]) : sc[(size_t)a * HW + hw];   // the key carries the probability
-      // :124-149 shifted anchor: float64 add of exactly representable values, rounded to float32 (:54) -> exact
-      const float sx = (float)w * L.feat_stride, sy = (float)h * L.feat_stride;
-      const float ax1 = L.anchors[a * 4 + 0] + sx, ay1 = L.anchors[a * 4 + 1] + sy;
-      const float ax2 = L.anchors[a * 4 + 2] + sx, ay2 = L.anchors[a * 4 + 3] + sy;
-      const float* d = dl + (size_t)(a * 4) * HW + hw;
-      decode_box(ax1, ay1, ax2, ay2, d[0], d[HW], d[2 * HW], d[3 * HW], box);
-      box[0] = clip1(box[0], p.im_w - 1.f); box[1] = clip1(box[1], p.im_h - 1.f);   // :230-236
-      box[2] = clip1(box[2], p.im_w - 1.f); box[3] = clip1(box[3], p.im_h - 1.f);
-      const float ws = box[2] - box[0] + 1.f, hs = box[3] - box[1] + 1.f;           // :155-156
-      const float xc = box[0] + fdiv(ws, 2.f), yc = box[1] + fdiv(hs, 2.f);         // :157-158
-      ok = (ws >= p.min_size) && (hs >= p.min_size) && (xc < p.im_w) && (yc < p.im_h);  // :159-162
-    }
-    // ordered compaction: wave ballot + cross-wave prefix
-    const uint64_t m = __ballot(ok);
-    const int wv = tid >> 6, lane = tid & 63;
-    if (lane == 0) wave_tot[wv] = __builtin_popcountll(m);
-    __syncthreads();
-    int base = running;
-    for (int q = 0; q < wv; q++) base += wave_tot[q];
-    if (ok) {
-      const int slot = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-      reinterpret_cast<float4*>(ob)[slot] = make_float4(box[0], box[1], box[2], box[3]);
-      os[slot] = s;
-    }
-    __syncthreads();
-    if (tid == 0) { int t = 0; for (int q = 0; q < kSortDecodeThreads / 64; q++) t += wave_tot[q]; running += t; }
-    __syncthreads();
+  const int k = blk * kDecodeThreads + tid;
+  bool ok = false;
+  float box[4] = {0.f, 0.f, 0.f, 0.f};
+  float s = 0.f;
+  if (k < n_rank) {
+    const uint64_t key = sk[k];
+    const uint32_t n = desc_key_index(key);
+    const int a = n % L.A, hw = n / L.A;
+    const int h = hw / L.W, w = hw - h * L.W;
+    s = L.logit ? desc_key_score(key) : sc[(size_t)a * HW + hw];   // the key carries the probability
+    // :124-149 shifted anchor: float64 add of exactly representable values, rounded to float32 (:54) -> exact
+    const float sx = (float)w * L.feat_stride, sy = (float)h * L.feat_stride;
+    const float ax1 = L.anchors[a * 4 + 0] + sx, ay1 = L.anchors[a * 4 + 1] + sy;
+    const float ax2 = L.anchors[a * 4 + 2] + sx, ay2 = L.anchors[a * 4 + 3] + sy;
+    const float* d = dl + (size_t)(a * 4) * HW + hw;
+    decode_box(ax1, ay1, ax2, ay2, d[0], d[HW], d[2 * HW], d[3 * HW], box);
+    box[0] = clip1(box[0], p.im_w - 1.f); box[1] = clip1(box[1], p.im_h - 1.f);   // :230-236
+    box[2] = clip1(box[2], p.im_w - 1.f); box[3] = clip1(box[3], p.im_h - 1.f);
+    const float ws = box[2] - box[0] + 1.f, hs = box[3] - box[1] + 1.f;           // :155-156
+    const float xc = box[0] + fdiv(ws, 2.f), yc = box[1] + fdiv(hs, 2.f);         // :157-158
+    ok = (ws >= p.min_size) && (hs >= p.min_size) && (xc < p.im_w) && (yc < p.im_h);  // :159-162
   }
-  if (tid == 0) p.out_counts[seg] = running;
-  DTC_PT(3, seg, 3);
+  const uint64_t m = __ballot(ok);
+  if (lane == 0) wave_tot[wv] = __builtin_popcountll(m);
+  __syncthreads();
+  uint32_t* bc = p.blk_cnt + (size_t)seg * p.dec_blocks;
+  if (wv == 0) {
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < kDecodeThreads / 64; q++) mine += wave_tot[q];
+    if (lane == 0) __hip_atomic_store(&bc[blk], ((uint32_t)mine << 1) | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // survivors of the blocks before this one: lane t polls block t (their tickets are lower: those workgroups are running)
+    int before = 0;
+    for (int t0 = 0; t0 < blk; t0 += 64) {
+      const int t = t0 + lane;
+      uint32_t v = 1u;
+      if (t < blk) {
+        do { v = __hip_atomic_load(&bc[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); if (!(v & 1u)) __builtin_amdgcn_s_sleep(1); } while (!(v & 1u));
+      }
+      int c = t < blk ? (int)(v >> 1) : 0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+      before += c;
+    }
+    if (lane == 0) {
+      sh_base = before;
+      if (blk == p.dec_blocks - 1) p.out_counts[seg] = before + mine;       // the last block closes the segment
+    }
+  }
+  __syncthreads();
+  int base = sh_base;
+  for (int q = 0; q < wv; q++) base += wave_tot[q];
+  if (ok) {
+    const int slot = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    reinterpret_cast<float4*>(ob)[slot] = make_float4(box[0], box[1], box[2], box[3]);
+    os[slot] = s;
+  }
 }
 
 // After NMS: gather the kept proposals of every segment.  keep [S, keep_stride] positions into the sorted boxes.
@@ -395,8 +440,8 @@ __global__ void rpn_gather_kept_kernel(const float4* __restrict__ boxes, const f
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
 struct RpnPlan {
-  int chunks_per_image, ties_per_image, k_stride, n_seg;
-  size_t off_hist, off_counters, off_gt, off_tie, total;
+  int chunks_per_image, ties_per_image, k_stride, n_seg, dec_blocks;
+  size_t off_hist, off_counters, off_ticket, off_blk, off_gt, off_tie, off_sorted, off_nrank, total;
 };
 
 static int make_plan(const dtc_rpn_level* levels, int n_levels, int batch, int k_stride, RpnParams* p, RpnPlan* plan) {
@@ -424,10 +469,16 @@ static int make_plan(const dtc_rpn_level* levels, int n_levels, int batch, int k
   const int S = batch * n_levels;
   plan->chunks_per_image = chunks; plan->ties_per_image = ties; plan->k_stride = k_stride; plan->n_seg = S;
   size_t o = 0;
+  plan->dec_blocks = (k_stride + kDecodeThreads - 1) / kDecodeThreads;
+  // [histograms | counters | tickets | block counts]: ONE clearing launch covers everything up to off_gt
   plan->off_hist = o; o += al((size_t)S * 2 * kHistBins * sizeof(uint32_t));
   plan->off_counters = o; o += al((size_t)S * 2 * sizeof(uint32_t));
+  plan->off_ticket = o; o += al((size_t)S * sizeof(uint32_t));
+  plan->off_blk = o; o += al((size_t)S * plan->dec_blocks * sizeof(uint32_t));
   plan->off_gt = o; o += al((size_t)S * k_stride * sizeof(uint64_t));
   plan->off_tie = o; o += al((size_t)batch * ties * sizeof(uint64_t));
+  plan->off_sorted = o; o += al((size_t)S * k_stride * sizeof(uint64_t));
+  plan->off_nrank = o; o += al((size_t)S * sizeof(int32_t));
   plan->total = o;
   return DTC_OK;
 }
@@ -458,9 +509,14 @@ DTC_API int dtc_rpn_topk_decode(const dtc_rpn_level* levels, int n_levels, int b
   p.counters = reinterpret_cast<uint32_t*>(w + plan.off_counters);
   p.gt_keys = reinterpret_cast<uint64_t*>(w + plan.off_gt);
   p.cand_keys = reinterpret_cast<uint64_t*>(w + plan.off_tie);
+  p.sorted_keys = reinterpret_cast<uint64_t*>(w + plan.off_sorted);
+  p.n_rank = reinterpret_cast<int32_t*>(w + plan.off_nrank);
+  p.ticket = reinterpret_cast<uint32_t*>(w + plan.off_ticket);
+  p.blk_cnt = reinterpret_cast<uint32_t*>(w + plan.off_blk);
+  p.dec_blocks = plan.dec_blocks;
   p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_counts = out_counts;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  // histograms + counters are contiguous at the start of the workspace
+  // histograms + counters + tickets + block counts are contiguous at the start of the workspace
   if (dtc::zero_async(w, plan.off_gt, s) != DTC_OK) return DTC_ELAUNCH;     // a kernel node, never hipMemsetAsync (dtc_common.h)
   const dim3 grid(plan.chunks_per_image, batch), blk(dtc::kHistThreads);
   hipLaunchKernelGGL(dtc::rpn_hist_kernel<0>, grid, blk, 0, s, p);
@@ -470,9 +526,10 @@ DTC_API int dtc_rpn_topk_decode(const dtc_rpn_level* levels, int n_levels, int b
   const int sort_cap = dtc::next_pow2(plan.k_stride) <= 1024 ? 2048 : dtc::next_pow2(plan.k_stride);
   const size_t smem = (size_t)sort_cap * sizeof(uint64_t);
   if (smem > 32 * 1024) {   // static __shared__ of the kernel comes on top: raise the limit well before dynamic + static reaches 64 KB
-    DTC_RAISE_LDS_ONCE(dtc::rpn_sort_decode_kernel, 144 * 1024);
+    DTC_RAISE_LDS_ONCE(dtc::rpn_sort_kernel, 144 * 1024);
   }
-  hipLaunchKernelGGL(dtc::rpn_sort_decode_kernel, dim3(plan.n_seg), dim3(dtc::kSortDecodeThreads), smem, s, p, sort_cap);
+  hipLaunchKernelGGL(dtc::rpn_sort_kernel, dim3(plan.n_seg), dim3(dtc::kSortDecodeThreads), smem, s, p, sort_cap);
+  hipLaunchKernelGGL(dtc::rpn_decode_kernel, dim3(plan.dec_blocks, plan.n_seg), dim3(dtc::kDecodeThreads), 0, s, p);
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }

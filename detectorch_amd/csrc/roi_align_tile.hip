@@ -605,376 +605,6 @@ extern "C" __attribute__((visibility("default"))) int dtc_debug_tile_trace(void*
 namespace dtc {
 #endif
 
-// =============================================================================================================================
-// Round 5: the float32 instantiation, restructured (roi_align_fwd_tile2).  Same clusters, same arithmetic, same results bit for bit.
-//
-// What the round-4 counters say about the kernel above on float32 maps (profiles/r04_k_cluster_kernel_sq_counters.json, corrected
-// reading: SQ_LDS_IDX_ACTIVE already contains SQ_LDS_BANK_CONFLICT): LDS array 51 % busy, VALU 40 %, waves parked 47 % of their
-// cycles at 2.5 waves per SIMD (162 VGPRs, 52 KB: three workgroups per CU) with TWO workgroup barriers per pass -- the phases of a
-// workgroup (commit | pool) never overlap each other, only other workgroups fill the gaps.  This form removes both limits:
-//   * ONE channel quad per pass and TWO LDS images: the wave commits quad q+1 into the other image, issues the loads of quad q+2,
-//     pools quad q, stores the slab of quad q-1 -- ONE barrier per pass, commit (LDS store path) and pooling (LDS reads + VALU) of
-//     the same workgroup overlap across its waves;
-//   * four (not eight) 16-byte pieces in flight per thread, 4 tap base addresses instead of 16 (the image has NO pad slots: x.hi is
-//     the next slot = an immediate offset, y.hi the next row = one uniform add), so the kernel fits 128 VGPRs, and with one quad
-//     per image 40 KB of LDS hold hdr + 2 slabs + 2 images: FOUR workgroups per CU;
-//   * image rows are P = 4 * ngx + 1 slots apart (odd) and a wave-instruction stages a 4-row x 4-piece block (not 16 consecutive
-//     pieces): the transposing ds_write_b32 of 32 lanes then hit 16 distinct banks two-way, which is free (MI355X_MICROARCH.md,
-//     LDS) -- the pad slot every 8 pixels that did this job above is what made the tap offsets irregular;
-//   * the clamped taps of the reference (x.lo == x.hi == W - 1, y.lo == y.hi == H - 1: roi_align_cpu_loop.cpp:78-90) read the
-//     next slot / next row like every other tap, so a window that touches the right / bottom edge of its map stages a DUPLICATE of
-//     the last column (slot 4 * ngx of a row, the odd pitch's spare slot) / last row (one more image row, source row clamped):
-//     the reference multiplies the same value by the same zero weight.
-// Float32 maps whose levels can all be staged with 16-byte pieces (the FPN box / mask heads on NCHW maps); everything else --
-// 16-bit maps, strided levels, channel tails -- stays on the kernel above.  A/B: DTC_RA_TILE2=0.
-// =============================================================================================================================
-constexpr int kT2MaxK = 16;                                                                  // RoIs per workgroup (7 x 7 bins: 5 / 10)
-constexpr int kT2Hdr = (kT2MaxK * (kTileRoiBytes + kTileGroupBytes) + 16 + 15) & ~15;
-enum { kGrpBig = 4 };                        // one RoI whose window needs both images as one (single-buffered, two barriers per pass)
-// Workgroup shapes: 256 threads, K = 5 RoIs of 7 x 7 bins, 40 KB -> four workgroups per CU; 512 threads, K = 10, 80 KB -> two per CU
-// (the same 16 waves per CU; twice the RoIs share a staged patch: wider patches = fewer partly used 128-byte lines per RoI).
-template <int NT> struct T2Shape;
-template <> struct T2Shape<256> { static constexpr int kLdsKB = 40; };
-template <> struct T2Shape<512> { static constexpr int kLdsKB = 80; };
-
-struct T2Geom { int y0, x0a, ngx, nbx, nblk, ths, P, dupcol, H, bcl; };   // bcl: log2 pieces per block row (2: 4 x 4 blocks, 3: 2 x 8)
-struct T2Item {
-  int a[2][2];            // byte offset of the slot (y.lo, x.lo) of sample (iy, ix) inside an image
-  float yh[2], yl[2], xh[2], xl[2];
-  bool on;
-};
-
-// staging units of a thread.  The window is cut into blocks of 16 pieces (4 rows x 4 pieces, or 2 rows x 8), one block x 4 channels
-// per wave-instruction; blocks 2j and 2j + 1 (horizontal neighbours: the two halves of the same 128-byte lines) are units 2i and
-// 2i + 1 of ONE wave, issued back to back.
-template <int KC, int NW, bool UNAL>
-__device__ __forceinline__ void t2_decode(const T2Geom& g, const dtc_feat_level& L, int blk0, uint32_t (&uoff)[KC], int (&ulds)[KC]) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, pl = lane & 15, cl = (lane >> 4) & 3;
-  const int sh32 = (int)L.stride_h, sc32 = (int)L.stride_c;
-  const float rinv = 1.0f / (float)g.nbx;
-  const int bcl = g.bcl, brl = 4 - bcl;
-#pragma unroll
-  for (int i = 0; i < KC; i++) {
-    const int blk = min(blk0 + 2 * (wv + NW * (i >> 1)) + (i & 1), g.nblk - 1);   // past the window: duplicate its last block
-    const int by = (int)(((float)blk + 0.5f) * rinv);            // exact: blk < 2^10, distance to an integer >= 0.5 / nbx
-    const int bx = blk - by * g.nbx;
-    const int row = min((by << brl) + (pl >> bcl), g.ths - 1);
-    const int gx = min((bx << bcl) + (pl & ((1 << bcl) - 1)), g.ngx - 1);
-    int col = g.x0a + 4 * gx, sft = 0;
-    if (UNAL) { sft = max(0, col + 3 - (L.width - 1)); col -= sft; }   // last piece of a row: stay in the row
-    const int srow = min(g.y0 + row, g.H - 1);                   // the duplicate of the map's last row
-    const uint32_t last = (g.dupcol && gx == g.ngx - 1) ? 1u : 0u;
-    uoff[i] = ((uint32_t)(srow * sh32 + col + cl * sc32) * 4u) | (last << 29) | ((uint32_t)sft << 30);
-    ulds[i] = ((row * g.P + 4 * gx) << 4) + (cl << 2);
-  }
-}
-
-template <int KC>
-__device__ __forceinline__ void t2_issue(__amdgpu_buffer_rsrc_t srd, const uint32_t (&uoff)[KC], uint32_t soff, float4 (&v)[KC]) {
-#pragma unroll
-  for (int i = 0; i < KC; i++) v[i] = Piece4<float>::ld(srd, uoff[i] & 0x1fffffffu, soff);
-}
-
-template <int KC, bool UNAL>
-__device__ __forceinline__ void t2_commit(unsigned char* img, bool dupcol, const uint32_t (&uoff)[KC], const int (&ulds)[KC], const float4 (&v)[KC]) {
-#pragma unroll
-  for (int i = 0; i < KC; i++) {
-    float4 w = v[i];
-    if (UNAL) {                               // shifted piece: pixel k of the piece is component k + shift of the load
-      const uint32_t sft = uoff[i] >> 30;
-      w.x = sft == 0 ? w.x : sft == 1 ? w.y : sft == 2 ? w.z : w.w;
-      w.y = sft == 0 ? w.y : sft == 1 ? w.z : w.w;
-      w.z = sft == 0 ? w.z : w.w;             // components past the row end hold a copy of its last pixel (the clamped taps read it)
-    }
-    float* d = reinterpret_cast<float*>(img + ulds[i]);
-    d[0] = w.x; d[4] = w.y; d[8] = w.z; d[12] = w.w;
-  }
-  if (dupcol) {                               // uniform: only windows on the right edge of their map
-#pragma unroll
-    for (int i = 0; i < KC; i++)
-      if (uoff[i] & (1u << 29)) reinterpret_cast<float*>(img + ulds[i])[16] = v[i].w;     // duplicate of column W - 1 in the spare slot
-  }
-}
-
-// pool the lane's (RoI, bin) from one image into the slab [RoI][4 channels][bins]
-__device__ __forceinline__ void t2_pool(const unsigned char* img, int row_bytes, const T2Item& it, float* so, int bins) {
-  f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-  // reference order: for iy { for ix { acc += w1*v1 + w2*v2 + w3*v3 + w4*v4 } }   (roi_align_cpu_loop.cpp:203-214)
-#pragma unroll
-  for (int iy = 0; iy < 2; iy++) {
-#pragma unroll
-    for (int ix = 0; ix < 2; ix++) {
-      const unsigned char* lo = img + it.a[iy][ix];
-      const unsigned char* hi = lo + row_bytes;
-      const f32x4 t0 = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(lo, 16));
-      const f32x4 t1 = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(lo + 16, 16));
-      const f32x4 t2 = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(hi, 16));
-      const f32x4 t3 = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(hi + 16, 16));
-      const float w1 = it.yh[iy] * it.xh[ix], w2 = it.yh[iy] * it.xl[ix];             // roi_align_cpu_loop.cpp:95
-      const float w3 = it.yl[iy] * it.xh[ix], w4 = it.yl[iy] * it.xl[ix];
-      a01 += w1 * t0.lo + w2 * t1.lo + w3 * t2.lo + w4 * t3.lo;    // :208-211
-      a23 += w1 * t0.hi + w2 * t1.hi + w3 * t2.hi + w4 * t3.hi;
-    }
-  }
-  // :216  output_val /= count ; count == 4 -> x * 0.25f is the same float32
-  so[0] = a01.x * 0.25f; so[bins] = a01.y * 0.25f; so[2 * bins] = a23.x * 0.25f; so[3 * bins] = a23.y * 0.25f;
-}
-
-// One cluster whose window fits ONE image, every channel quad of the block: commit(q+1) | issue(q+2) | pool(q) | store(q-1) | barrier.
-template <typename TOut, int KC, int NW, bool UNAL>
-__device__ __forceinline__ void t2_passes(const dtc_feat_level& L, const float* fbase, int nq_tot, int bins, unsigned char* smem, int slab_b,
-                                          int buf_b, const T2Geom& g, const T2Item& it, int rl, int bin, TOut* out_lane, int q_out_stride) {
-  uint32_t uoff[KC];
-  int ulds[KC];
-  float4 v[KC];
-  t2_decode<KC, NW, UNAL>(g, L, 0, uoff, ulds);
-  const __amdgpu_buffer_rsrc_t srd = make_srd(fbase);
-  const uint32_t quad_bytes = (uint32_t)(L.stride_c * (int64_t)16);                 // four channels
-  unsigned char* slab0 = smem + kT2Hdr;
-  unsigned char* img0 = slab0 + 2 * slab_b;
-  const int row_bytes = g.P << 4;
-  const int so_off = (rl * (4 * bins) + bin) * 4;
-  const bool dupcol = g.dupcol != 0;
-  t2_issue<KC>(srd, uoff, 0u, v);
-  t2_commit<KC, UNAL>(img0, dupcol, uoff, ulds, v);
-  if (nq_tot > 1) t2_issue<KC>(srd, uoff, quad_bytes, v);
-  __syncthreads();
-#pragma unroll 1
-  for (int q = 0; q < nq_tot; q++) {
-    const int cur = uni(q & 1);
-    unsigned char* img_cur = img0 + cur * buf_b;
-    unsigned char* img_nxt = img0 + (cur ^ 1) * buf_b;
-    if (q + 1 < nq_tot) {
-      t2_commit<KC, UNAL>(img_nxt, dupcol, uoff, ulds, v);
-      if (q + 2 < nq_tot) t2_issue<KC>(srd, uoff, (uint32_t)(q + 2) * quad_bytes, v);
-    }
-    if (it.on) {
-      t2_pool(img_cur, row_bytes, it, reinterpret_cast<float*>(slab0 + cur * slab_b + so_off), bins);
-      if (q > 0) store_quad<TOut>(out_lane + (size_t)(q - 1) * q_out_stride, reinterpret_cast<const float4*>(slab0 + (cur ^ 1) * slab_b)[threadIdx.x]);
-    }
-    __syncthreads();
-  }
-  if (it.on) store_quad<TOut>(out_lane + (size_t)(nq_tot - 1) * q_out_stride, reinterpret_cast<const float4*>(slab0 + ((nq_tot - 1) & 1) * slab_b)[threadIdx.x]);
-}
-
-// One RoI whose window needs both images as one: staged in rounds of 4 units per thread, no prefetch, two barriers per pass (rare:
-// a box that covers most of the coarsest map).
-template <typename TOut, int NW>
-__device__ __forceinline__ void t2_passes_big(const dtc_feat_level& L, const float* fbase, int nq_tot, int bins, unsigned char* smem, int slab_b,
-                                              const T2Geom& g, const T2Item& it, int rl, int bin, TOut* out_lane, int q_out_stride) {
-  constexpr int KC = 4;
-  const __amdgpu_buffer_rsrc_t srd = make_srd(fbase);
-  const uint32_t quad_bytes = (uint32_t)(L.stride_c * (int64_t)16);
-  unsigned char* slab0 = smem + kT2Hdr;
-  unsigned char* img0 = slab0 + 2 * slab_b;
-  const int row_bytes = g.P << 4;
-  const int so_off = (rl * (4 * bins) + bin) * 4;
-#pragma unroll 1
-  for (int q = 0; q < nq_tot; q++) {
-    const int cur = uni(q & 1);
-#pragma unroll 1
-    for (int b0 = 0; b0 < g.nblk; b0 += NW * KC) {
-      uint32_t uoff[KC];
-      int ulds[KC];
-      float4 v[KC];
-      t2_decode<KC, NW, true>(g, L, b0, uoff, ulds);             // (the shifted-piece form covers aligned rows too: shift 0)
-      t2_issue<KC>(srd, uoff, (uint32_t)q * quad_bytes, v);
-      t2_commit<KC, true>(img0, g.dupcol != 0, uoff, ulds, v);
-    }
-    __syncthreads();
-    if (it.on) {
-      t2_pool(img0, row_bytes, it, reinterpret_cast<float*>(slab0 + cur * slab_b + so_off), bins);
-      if (q > 0) store_quad<TOut>(out_lane + (size_t)(q - 1) * q_out_stride, reinterpret_cast<const float4*>(slab0 + (cur ^ 1) * slab_b)[threadIdx.x]);
-    }
-    __syncthreads();
-  }
-  if (it.on) store_quad<TOut>(out_lane + (size_t)(nq_tot - 1) * q_out_stride, reinterpret_cast<const float4*>(slab0 + ((nq_tot - 1) & 1) * slab_b)[threadIdx.x]);
-}
-
-template <typename TOut, int NT>
-__global__ __launch_bounds__(NT, 4) void roi_align_fwd_tile2(RoiAlignParams p, int kgroup, int lds_bytes, int merge_pct, int reverse, int bcl) {
-  constexpr int NW = NT / 64;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  TileRoi* troi = reinterpret_cast<TileRoi*>(smem);
-  TileGroup* tgrp = reinterpret_cast<TileGroup*>(smem + kT2MaxK * kTileRoiBytes);
-  int* ngp = reinterpret_cast<int*>(smem + kT2MaxK * (kTileRoiBytes + kTileGroupBytes));
-  // [header][slab 0][slab 1][image 0][image 1]: slab = K RoIs x 4 channels x bins float32; image = one channel quad of a window
-  const int bins = p.pooled_h * p.pooled_w;
-  const int slab_b = kgroup * bins * 16;
-  const int buf_b = ((lds_bytes - kT2Hdr - 2 * slab_b) >> 1) & ~15;
-  const int buf_slots = buf_b >> 4;
-  const int tid = threadIdx.x;
-  const int nct = ceil_div(p.channels, p.ch_block);
-  int wi = tile_work_item(blockIdx.x, gridDim.x, reverse);
-  int grp = wi / nct;
-  int c0 = (wi - grp * nct) * p.ch_block;
-  {
-    const int ngrp = (int)gridDim.x / nct;        // an XCD walks its groups once per channel block (see roi_align_fwd_tile)
-    if ((reverse & 4) && ngrp % kXcds == 0 && ngrp >= 2 * kXcds) {
-      const int x = blockIdx.x % kXcds, j = blockIdx.x / kXcds, ngx = ngrp / kXcds;
-      const int cbi = j / ngx, gl = j - cbi * ngx;
-      grp = x * ngx + ((reverse & 1) ? ngx - 1 - gl : gl);
-      c0 = cbi * p.ch_block;
-    }
-  }
-  const int nc = min(p.ch_block, p.channels - c0);       // multiple of 4 (host)
-  const int K = kgroup;
-  const int brl = 4 - bcl;
-
-  // window -> (slots of an image, blocks of 16 pieces); H: the level's height
-  auto shape = [bcl, brl](int x0, int x1, int y0, int y1, int H, int& slots, int& nblk) {
-    const int ngx = (x1 >> 2) - (x0 >> 2) + 1, ths = y1 - y0 + 1 + (y1 >= H - 1 ? 1 : 0);
-    slots = ths * (4 * ngx + 1);
-    nblk = ((ngx + (1 << bcl) - 1) >> bcl) * ((ths + (1 << brl) - 1) >> brl);
-  };
-  // ---- A + B (wavefront 0): windows, then greedy clustering along the visiting order (as in roi_align_fwd_tile) -------------------
-  if (tid < 64) {
-    TileRoi t;
-    t.lvl = -1; t.b = 0; t.x0 = t.x1 = t.y0 = t.y1 = 0; t.r = 0; t.valid = 0; t.sh = t.sw = 0.f; t.bin_h = t.bin_w = 1.f;
-    int lvH = 1;
-    const int ri = grp * K + tid;
-    if (tid < K && ri < p.n_rois) {
-      const RoiHead hd = load_roi_head(p, ri);
-      t.valid = 1; t.r = hd.r; t.b = hd.b; t.sh = hd.sh; t.sw = hd.sw; t.bin_h = hd.bin_h; t.bin_w = hd.bin_w;
-      if (hd.lvl >= 0 && hd.lvl < p.n_levels) {
-        t.lvl = hd.lvl;
-        const int H = p.lv[hd.lvl].height, W = p.lv[hd.lvl].width;
-        lvH = H;
-        t.y0 = make_axis(hd.sh, hd.bin_h, 0, 0, 2, H).lo;
-        t.y1 = make_axis(hd.sh, hd.bin_h, p.pooled_h - 1, 1, 2, H).hi;
-        t.x0 = make_axis(hd.sw, hd.bin_w, 0, 0, 2, W).lo;
-        t.x1 = make_axis(hd.sw, hd.bin_w, p.pooled_w - 1, 1, 2, W).hi;
-      }
-    }
-    if (tid < K) troi[tid] = t;
-    auto bc = [](int v, int k) { return __builtin_amdgcn_readlane(v, k); };     // k: uniform lane index
-    int ng = 0, k = 0;
-    while (k < K) {
-      const int ks = uni(k);
-      const int a_lvl = bc(t.lvl, ks), a_b = bc(t.b, ks), a_valid = bc(t.valid, ks), a_H = bc(lvH, ks);
-      const int a_x0 = bc(t.x0, ks), a_x1 = bc(t.x1, ks), a_y0 = bc(t.y0, ks), a_y1 = bc(t.y1, ks);
-      TileGroup g;
-      g.first = k; g.count = 1; g.x0 = a_x0; g.x1 = a_x1; g.y0 = a_y0; g.y1 = a_y1; g.pad = 0;
-      if (!a_valid) g.kind = kGrpAbsent;
-      else if (a_lvl < 0) g.kind = kGrpZero;
-      else {
-        int slots0, nblk0;
-        shape(a_x0, a_x1, a_y0, a_y1, a_H, slots0, nblk0);
-        if (bins > NT || slots0 > 2 * buf_slots) g.kind = kGrpGather;
-        else if (slots0 > buf_slots || nblk0 > 6 * NW) g.kind = kGrpBig;
-        else {
-          g.kind = kGrpPool;
-          long long sum_px = (long long)(a_y1 - a_y0 + 1) * (a_x1 - a_x0 + 1);
-          while (k + g.count < K && (g.count + 1) * bins <= NT) {
-            const int js = uni(k + g.count);
-            const int n_lvl = bc(t.lvl, js), n_b = bc(t.b, js), n_valid = bc(t.valid, js);
-            if (!n_valid || n_lvl != a_lvl || n_b != a_b) break;
-            const int n_x0 = bc(t.x0, js), n_x1 = bc(t.x1, js), n_y0 = bc(t.y0, js), n_y1 = bc(t.y1, js);
-            const int ux0 = min(g.x0, n_x0), ux1 = max(g.x1, n_x1), uy0 = min(g.y0, n_y0), uy1 = max(g.y1, n_y1);
-            int uslots, unblk;
-            shape(ux0, ux1, uy0, uy1, a_H, uslots, unblk);
-            if (uslots > buf_slots || unblk > 4 * NW) break;   // merged clusters keep to four units per thread
-            const long long n_px = (long long)(n_y1 - n_y0 + 1) * (n_x1 - n_x0 + 1);
-            const long long u_px = (long long)(uy1 - uy0 + 1) * (ux1 - ux0 + 1);
-            if (u_px * 100 > (sum_px + n_px) * merge_pct) break;
-            g.x0 = ux0; g.x1 = ux1; g.y0 = uy0; g.y1 = uy1; g.count++;
-            sum_px += n_px;
-          }
-        }
-      }
-      if (tid == 0) tgrp[ng] = g;
-      ng++;
-      k += g.count;
-    }
-    if (tid == 0) *ngp = ng;
-  }
-  __syncthreads();
-
-  // ---- C. clusters ----------------------------------------------------------------------------------------------------
-  const int ngroups = uni(*ngp);
-  for (int gi = 0; gi < ngroups; gi++) {
-    const int first = uni(tgrp[gi].first), count = uni(tgrp[gi].count), kind = uni(tgrp[gi].kind);
-    if (kind == kGrpAbsent) continue;
-    if (kind == kGrpZero) {    // padding row of a fixed-shape batch (fpn.hip emits level -1): defined output
-      TOut* oz = reinterpret_cast<TOut*>(p.out) + ((size_t)uni(troi[first].r) * p.channels + c0) * bins;
-      for (int o = tid; o < nc * bins; o += NT) oz[o] = from_f32<TOut>(0.f);
-      continue;
-    }
-    const int lvl = uni(troi[first].lvl), b = uni(troi[first].b);
-    const dtc_feat_level L = p.lv[lvl];
-    const float* fbase = reinterpret_cast<const float*>(L.data) + (int64_t)b * L.stride_n + (int64_t)c0 * L.stride_c;
-    if (kind == kGrpGather) {
-      // a single window larger than both LDS images: per-output gather straight from global memory, geometry on the fly
-      const RoiHead hd = load_roi_head(p, grp * K + first);
-      TOut* og = reinterpret_cast<TOut*>(p.out) + ((size_t)hd.r * p.channels + c0) * bins;
-      for (int o = tid; o < nc * bins; o += NT) {
-        const int c = o / bins, bin = o - c * bins;
-        const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
-        const float* d = fbase + (int64_t)c * L.stride_c;
-        float acc = 0.f;
-        for (int iy = 0; iy < 2; iy++) {
-          const AxisEntry y = make_axis(hd.sh, hd.bin_h, ph, iy, 2, L.height);
-          const int64_t ylo = (int64_t)y.lo * L.stride_h, yhi = (int64_t)y.hi * L.stride_h;
-          for (int ix = 0; ix < 2; ix++) {
-            const AxisEntry x = make_axis(hd.sw, hd.bin_w, pw, ix, 2, L.width);
-            const int64_t xlo = (int64_t)x.lo * L.stride_w, xhi = (int64_t)x.hi * L.stride_w;
-            const float w1 = y.h * x.h, w2 = y.h * x.l, w3 = y.l * x.h, w4 = y.l * x.l;
-            acc += w1 * d[ylo + xlo] + w2 * d[ylo + xhi] + w3 * d[yhi + xlo] + w4 * d[yhi + xhi];
-          }
-        }
-        og[o] = from_f32<TOut>(acc * 0.25f);
-      }
-      continue;
-    }
-    // cluster geometry (uniform)
-    const int gx0 = uni(tgrp[gi].x0), gx1 = uni(tgrp[gi].x1), gy0 = uni(tgrp[gi].y0), gy1 = uni(tgrp[gi].y1);
-    T2Geom g;
-    g.H = L.height; g.bcl = bcl;
-    g.y0 = gy0; g.x0a = gx0 & ~3;
-    g.ngx = (gx1 >> 2) - (gx0 >> 2) + 1;
-    g.ths = gy1 - gy0 + 1 + (gy1 >= L.height - 1 ? 1 : 0);
-    g.P = 4 * g.ngx + 1;
-    g.nbx = (g.ngx + (1 << bcl) - 1) >> bcl;
-    g.nblk = g.nbx * ((g.ths + (1 << brl) - 1) >> brl);
-    g.dupcol = g.x0a + 4 * g.ngx == L.width ? 1 : 0;
-    // 16-byte aligned rows -> plain 16-byte pieces; 4-byte aligned rows (width % 4 != 0: P5's 42 columns) -> unaligned pieces, the
-    // last one of a row shifted left (the host launches this kernel only when every level is one or the other)
-    const bool al16 = ((L.width | L.stride_h | L.stride_c | L.stride_n) & 3) == 0 && (reinterpret_cast<uintptr_t>(L.data) & 15) == 0;
-    // ---- the lane's item -------------------------------------------------------------------------------------------
-    T2Item it;
-    it.on = tid < count * bins;
-    const int itx = it.on ? tid : 0;
-    const int rl = itx / bins, bin = itx - rl * bins;
-    const int ph = bin / p.pooled_w, pw = bin - ph * p.pooled_w;
-    const TileRoi hd = troi[first + rl];     // sh / sw / bin sizes as phase A formed them
-    int yrow[2], xcol[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const AxisEntry ey = make_axis(hd.sh, hd.bin_h, ph, i, 2, L.height);
-      const AxisEntry ex = make_axis(hd.sw, hd.bin_w, pw, i, 2, L.width);
-      it.yl[i] = ey.l; it.yh[i] = ey.h; it.xl[i] = ex.l; it.xh[i] = ex.h;
-      yrow[i] = (ey.lo - gy0) * g.P; xcol[i] = ex.lo - g.x0a;
-    }
-#pragma unroll
-    for (int iy = 0; iy < 2; iy++)
-#pragma unroll
-      for (int ix = 0; ix < 2; ix++) {
-        int t0 = (yrow[iy] + xcol[ix]) << 4;
-        asm volatile("" : "+v"(t0));           // one finished VGPR per sample: do not re-derive in the loop
-        it.a[iy][ix] = t0;
-      }
-    // the lane's 16 bytes of a slab = its 16 bytes of the output: float4 number `tid` of [RoI][4 channels][bins]
-    TOut* out_lane = reinterpret_cast<TOut*>(p.out) + ((size_t)hd.r * p.channels + c0) * bins + 4 * bin;
-    const int nq_tot = nc >> 2;
-    const int qs = 4 * bins;
-    if (kind == kGrpBig) t2_passes_big<TOut, NW>(L, fbase, nq_tot, bins, smem, slab_b, g, it, rl, bin, out_lane, qs);
-    else if (al16) {
-      if (g.nblk <= 4 * NW) t2_passes<TOut, 4, NW, false>(L, fbase, nq_tot, bins, smem, slab_b, buf_b, g, it, rl, bin, out_lane, qs);
-      else t2_passes<TOut, 6, NW, false>(L, fbase, nq_tot, bins, smem, slab_b, buf_b, g, it, rl, bin, out_lane, qs);
-    } else t2_passes<TOut, 6, NW, true>(L, fbase, nq_tot, bins, smem, slab_b, buf_b, g, it, rl, bin, out_lane, qs);
-  }
-}
-
 // ---- host side ------------------------------------------------------------------------------------------------------------
 struct TileConfig {
   int nt = 256;        // threads per workgroup
@@ -1029,65 +659,8 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   return DTC_OK;
 }
 
-// float32 maps on the restructured kernel (roi_align_fwd_tile2) when every level can be staged with 16-byte pieces
-static bool tile2_eligible(const RoiAlignParams& p) {
-  static const bool on = [] { const char* e = getenv("DTC_RA_TILE2"); return !(e && atoi(e) == 0); }();   // A/B knob, resolved once
-  if (!on || (p.channels & 3) || p.pooled_h * p.pooled_w > 256) return false;
-  for (int l = 0; l < p.n_levels; l++) {
-    const dtc_feat_level& L = p.lv[l];
-    if (L.stride_w != 1 || L.width < 4 || L.stride_h <= 0 || L.stride_c <= 0 || (reinterpret_cast<uintptr_t>(L.data) & 3)) return false;
-    if (L.stride_h * L.height + L.stride_c * 4 * 8 >= (1ll << 26)) return false;        // lane offsets + flags fit 32 bits
-  }
-  return true;
-}
-
-struct Tile2Config { int nt = 256, bcl = 2; };
-static const Tile2Config& tile2_config() {          // A/B knobs, resolved once: DTC_RA_TILE2_NT=256|512, DTC_RA_TILE2_BLOCK=2|3 (log2 pieces per block row)
-  static const Tile2Config cfg = [] {
-    Tile2Config c;
-    if (const char* e = getenv("DTC_RA_TILE2_NT")) { const int v = atoi(e); if (v == 256 || v == 512) c.nt = v; }
-    if (const char* e = getenv("DTC_RA_TILE2_BLOCK")) { const int v = atoi(e); if (v == 2 || v == 3) c.bcl = v; }
-    return c;
-  }();
-  return cfg;
-}
-
-template <typename TOut, int NT>
-static int launch_tile2_nt(RoiAlignParams p, hipStream_t stream) {
-  const TileConfig& cfg = tile_config();
-  const int bins = p.pooled_h * p.pooled_w;
-  int K = NT / bins;
-  K = K < 1 ? 1 : (K > kT2MaxK ? kT2MaxK : K);
-  const int lds_b = T2Shape<NT>::kLdsKB * 1024;
-  static std::once_flag once;
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_tile2<TOut, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  });
-  if (attr_rc != hipSuccess) return DTC_ELAUNCH;
-  const int ngrp = ceil_div(p.n_rois, K);
-  int cb = cfg.ch_block ? cfg.ch_block : ((long long)ngrp * ceil_div(p.channels, 128) >= 6144 ? 128 : 64);   // as launch_tile_nt
-  while (!cfg.ch_block && cb > 32 && (long long)ngrp * ceil_div(p.channels, cb) < 2048 * 256 / NT) cb >>= 1;
-  p.ch_block = cb;
-  const int nct = ceil_div(p.channels, p.ch_block);
-  hipLaunchKernelGGL((roi_align_fwd_tile2<TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, cfg.merge_pct,
-                     (cfg.reverse ? 1 : 0) | (p.xcd_remap ? 0 : 2) | (cfg.cb_major ? 4 : 0), tile2_config().bcl);
-  DTC_CHECK_LAUNCH();
-  return DTC_OK;
-}
-
-template <typename TOut>
-static int launch_tile2(const RoiAlignParams& p, hipStream_t stream) {
-  // 14 x 14 bins: one RoI per 256 threads already fills a workgroup; the wide shape is for the box head
-  if (tile2_config().nt == 512 && 2 * p.pooled_h * p.pooled_w <= 512) return launch_tile2_nt<TOut, 512>(p, stream);
-  return launch_tile2_nt<TOut, 256>(p, stream);
-}
-
 template <typename TIn, typename TOut>
 static int launch_tile_t(const RoiAlignParams& p, hipStream_t stream) {
-  if constexpr (sizeof(TIn) == 4) {
-    if (tile2_eligible(p)) return launch_tile2<TOut>(p, stream);
-  }
   return launch_tile_nt<TIn, TOut, 256>(p, stream);
 }
 

@@ -124,8 +124,8 @@ def test_fast_rcnn_fpn_precomputed_per_level_rois_and_restore_index(oracle):
                      use_rpn_head=False).cuda()
     seen = {}
     hk = model.conv_head.register_forward_hook(lambda m, i, o: seen.__setitem__("pooled", i[0].clone()))
-    image = torch.randn(1, 3, 320, 448, device="cuda")
-    boxes = synth.make_rois(synth.rng(9, 2), 83, im_h=320, im_w=448, min_side=10.0, max_side=440.0)
+    image = torch.randn(1, 3, 480, 640, device="cuda")
+    boxes = synth.make_rois(synth.rng(9, 2), 83, im_h=480, im_w=640, min_side=10.0, max_side=900.0)
     blobs = add_multilevel_rois_for_test({'rois': boxes}, 'rois')
     keys = ['rois_fpn2', 'rois_fpn3', 'rois_fpn4', 'rois_fpn5']
     assert all(len(blobs[k]) > 0 for k in keys)                       # every level is populated: a level swap cannot hide

@@ -93,6 +93,79 @@ def test_segmented_sorted_with_max_keep(hip, oracle):
         assert np.array_equal(keep[s, :cnt[s]], refs[s])
 
 
+def _c4_like_sorted_dets(seed, n, spread):
+    """n score-sorted boxes like the C4 RPN call's: anchors of a few shapes on a stride-16 grid, decoded with small deltas.  `spread`:
+    grid cells the boxes spread over -- few cells = heavy overlap (few survivors), many cells = most boxes survive."""
+    rs = synth.rng(41, seed)
+    shapes = np.array([[32, 32], [64, 64], [128, 128], [256, 256], [512, 512], [46, 23], [90, 45], [181, 90], [23, 46], [45, 90]], np.float32)
+    sh = shapes[rs.randint(0, len(shapes), n)] * np.exp(rs.normal(0, 0.2, (n, 2))).astype(np.float32)
+    cx = (rs.randint(0, spread, n) * 16 + rs.normal(0, 3, n)).astype(np.float32)
+    cy = (rs.randint(0, max(spread * 3 // 5, 1), n) * 16 + rs.normal(0, 3, n)).astype(np.float32)
+    b = np.stack([cx - sh[:, 0] / 2, cy - sh[:, 1] / 2, cx + sh[:, 0] / 2, cy + sh[:, 1] / 2], 1)
+    b = np.clip(b, 0, [1332, 799, 1332, 799]).astype(np.float32)
+    sc = np.sort(synth.dedupe_scores(rs.uniform(0, 1, n).astype(np.float32)))[::-1]
+    return np.ascontiguousarray(np.hstack([b, sc[:, None]]), np.float32)
+
+
+def test_two_phase_keep_max_keep_of_long_segments(hip, oracle):
+    """keep[:max_keep] of LONG sorted segments (the C4 RPN call, generate_proposals.py:114-117: 6000 boxes, 1000 kept): dtc_nms_sorted
+    first walks only the leading 2048 x 2048 corner of the suppression matrix and redoes a segment in full only if it has not kept
+    max_keep boxes by then.  One launch with every case side by side, keep lists bit-equal to the oracle's greedy walk:
+    a segment that reaches 1000 early (finished by the first phase), one whose 1000th survivor lies beyond row 2048 (second phase),
+    one that never reaches 1000 (second phase, fewer kept), a short one (<= 2048 rows: finished by the first phase whatever it
+    keeps) and an empty one."""
+    N, cap = 6000, 1000
+    segs = [_c4_like_sorted_dets(1, 6000, 84), _c4_like_sorted_dets(2, 6000, 10), _c4_like_sorted_dets(3, 6000, 6),
+            _c4_like_sorted_dets(4, 1500, 84), np.zeros((0, 5), np.float32), _c4_like_sorted_dets(5, 4100, 84)]
+    counts = [d.shape[0] for d in segs]
+    boxes = np.zeros((len(segs), N, 4), np.float32)
+    refs, last_rows = [], []
+    for s_, d in enumerate(segs):
+        boxes[s_, :d.shape[0]] = d[:, :4]
+        k = oracle.nms(d, 0.7, max_keep=cap) if d.shape[0] else np.zeros(0, np.int64)
+        refs.append(np.sort(k))
+        last_rows.append(int(refs[-1][-1]) if len(k) else -1)
+    # the cases this test exists for are really there
+    assert len(refs[0]) == cap and last_rows[0] < 2048
+    assert len(refs[1]) == cap and last_rows[1] >= 2048
+    assert len(refs[2]) < cap and counts[2] > 2048
+    keep, cnt = hip.nms_sorted(torch.from_numpy(boxes).cuda(), torch.tensor(counts, dtype=torch.int32).cuda(), 0.7, max_keep=cap)
+    keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+    for s_ in range(len(segs)):
+        assert cnt[s_] == len(refs[s_]), (s_, cnt[s_], len(refs[s_]))
+        assert np.array_equal(keep[s_, :cnt[s_]], refs[s_]), s_
+    # counts == NULL (every row valid) takes the same two phases
+    full = np.stack([segs[0][:, :4], segs[1][:, :4]])
+    keep, cnt = hip.nms_sorted(torch.from_numpy(full).cuda(), None, 0.7, max_keep=cap)
+    for s_ in range(2):
+        assert int(cnt[s_]) == cap and np.array_equal(keep[s_].cpu().numpy(), refs[s_])
+
+
+def test_negative_count_leaves_segment_untouched(hip, oracle):
+    """include/detectorch_hip.h: a NEGATIVE count marks a segment that is already reduced -- its keep / keep_count stay as they are
+    (what the second phase of the long-segment path relies on).  Mixed negative and positive counts, short segments (the LDS walk)
+    and long ones (the one-wave walk)."""
+    for N in (1000, 2500):
+        d0, d1 = _c4_like_sorted_dets(7, N, 84), _c4_like_sorted_dets(8, N - 100, 84)
+        boxes = np.zeros((3, N, 4), np.float32)
+        boxes[0] = d0[:, :4]; boxes[1] = d0[:, :4]; boxes[2, :N - 100] = d1[:, :4]
+        L = hip.lib()
+        dev = torch.device("cuda", 0)
+        ws = hip.workspace(L.dtc_nms_sorted_workspace_bytes(3, N), dev)
+        keep = torch.full((3, N), -7, dtype=torch.int32, device=dev)
+        cnt = torch.full((3,), -7, dtype=torch.int32, device=dev)
+        counts = torch.tensor([N, -1, N - 100], dtype=torch.int32, device=dev)
+        bt = torch.from_numpy(boxes).cuda()
+        hip.check(L.dtc_nms_sorted(bt.data_ptr(), counts.data_ptr(), 3, N, 0.7, 0, ws.data_ptr(), ws.numel(), keep.data_ptr(), N,
+                                   cnt.data_ptr(), hip.stream_ptr(dev)), "nms_sorted")
+        torch.cuda.synchronize()
+        keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+        r0, r2 = np.sort(oracle.nms(d0, 0.7)), np.sort(oracle.nms(d1, 0.7))
+        assert cnt[0] == len(r0) and np.array_equal(keep[0, :cnt[0]], r0)
+        assert cnt[2] == len(r2) and np.array_equal(keep[2, :cnt[2]], r2)
+        assert cnt[1] == -7 and (keep[1] == -7).all()
+
+
 def test_idempotence_full_size(hip):
     # size-independent property at BASELINE cfg2's full size (6000 pre-NMS boxes): NMS of the survivors keeps them all
     d = _dets(4242, 6000)

@@ -301,7 +301,7 @@ print("ok")
 @pytest.mark.parametrize("env", ["DTC_ROIALIGN_TILE=0", "DTC_ROIALIGN_GENERAL=1", "DTC_ROIALIGN_TILE=0 DTC_RA_NO_CTS64=1",
                                  "DTC_ROIALIGN_MAP=0",
                                  "DTC_ROIALIGN_NO_NHWC_DIRECT=1", "DTC_RA_TILE_CHBLOCK=128", "DTC_RA_TILE_CHBLOCK=32",
-                                 "DTC_RA_TILE_CBMAJOR=0", "DTC_RA_TILE2=0", "DTC_RA_NO_XCD=1", "DTC_RA_MAP_PREP=0", "DTC_RA_MAP_PITCH=0", "DTC_RA_TILE_LDS16_KB=52"])
+                                 "DTC_RA_TILE_CBMAJOR=0", "DTC_RA_NO_XCD=1", "DTC_RA_MAP_PREP=0", "DTC_RA_MAP_PITCH=0", "DTC_RA_TILE_LDS16_KB=52"])
 def test_kernel_variants_bit_exact_in_child_process(hip, oracle, env):
     """Every RoIAlign kernel that stays in the library -- the cluster-stationary default in its three workgroup shapes, the
     RoI-stationary LDS kernel with its stager options, the channels_last direct kernel, the per-output gather kernel -- does
@@ -671,12 +671,11 @@ def test_bf16_output_rounding_special_values(hip, oracle):
 
 
 @pytest.mark.parametrize("out_dtype", ["f32", "f16", "bf16"])
-def test_tile2_staging_paths(hip, oracle, out_dtype):
-    """The round-5 float32 cluster kernel (roi_align_fwd_tile2): every staging path against the oracle, bit-exact --
-    windows that need six units per thread (17-24 blocks of 4 x 4 pieces), a box over most of the coarsest map (both LDS images as
-    one, single-buffered), a box over the whole finest map (per-output gather), windows on the right / bottom edge of every level
-    (the duplicated last column / row that the clamped taps read; P5's 42 columns = unaligned pieces), clusters that merge and
-    clusters that cannot, on 7 x 7 and 14 x 14 bins, float32 / fp16 / bf16 output."""
+def test_cluster_kernel_window_shapes(hip, oracle, out_dtype):
+    """Window shapes of the cluster kernel against the oracle, bit-exact (written for the round-5 restructured kernel, commit 1e29752,
+    kept for the shipped one): wide and tall single windows, a box over most of the coarsest map, a box over the whole finest map
+    (per-output gather), windows on the right / bottom edge of every level (the clamped taps of roi_align_cpu_loop.cpp:78-90; P5's 42
+    columns = unaligned pieces), clusters that merge and clusters that cannot, 7 x 7 and 14 x 14 bins, float32 / fp16 / bf16 output."""
     rs = synth.rng(11, 5)
     shapes = synth.fpn_level_shapes()[:4]
     C = 16
