@@ -580,11 +580,11 @@ def main():
                                   "(profiles/r04_z_nhwc16_boxhead_counters.json, not measured in this run): 91 % L1 hits, texture data path (TD) "
                                   "83 % busy, VALU 59 % -- the floor of this formulation is the 64 B/clk/CU load-return path plus the reference's "
                                   "unfused multiply-adds, not HBM") if a.channels_last else
-                                 "two stacked floors (DESIGN 3.1, profiles/r04_a_*): the fabric -- the launch requests 2.3 x its algorithmic bytes "
-                                 "as L1 line fills, about half of which miss the XCD's L2 (fills that hit L2 run at ~22 TB/s, fills served by "
-                                 "the Infinity Cache / HBM at 6-8 TB/s) -- and the CU side: with the maps cache-resident and 81 % L2 hits the "
-                                 "same kernel still takes 0.30-0.35 ms (LDS pipe 77 % busy: tap gather with bank conflicts, transposing commit; "
-                                 "profiles/r04_k_cluster_kernel_sq_counters.json)"},
+                                 "bound by the vector L1's window of outstanding line fills, not by HBM bandwidth and not by a CU pipe (DESIGN 3.1, "
+                                 "tools/r05/README.md 2, profiles/r05_a_*): the launch requests 2.3 x its algorithmic bytes as 128-byte L1 fills, a CU keeps "
+                                 "~64-77 of them in flight, half hit the XCD's L2 (~250 cycles) and half go to the Infinity Cache / HBM (~1150 cycles): "
+                                 "fills x mean latency / fills in flight reproduces the launch time of every variant measured; LDS array 55 % busy "
+                                 "(SQ_LDS_IDX_ACTIVE, bank conflicts included), VALU 43 %, waves parked 46 % (recorded counters, not measured in this run)"},
             "consistency": {"timed_region_s": round(dt, 4), "one_stream_ms_per_step": None if one_stream_ms is None else round(one_stream_ms, 4),
                             "gathered_equals_local": gathered_ok,
                             "gathered_equals_recomputed": recomputed_ok,

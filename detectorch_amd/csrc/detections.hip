@@ -188,7 +188,10 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
   // of candidates (one 64-row block); as a separate launch pair (mask tiles + reduce over 640 segments) they cost 25 us of which
   // 20 were launch latency.  Blocks of 64 rows: (1) the four waves form the block's diagonal tile (16 rows each), (2) wave 0 walks
   // the block greedily with the bits removed by earlier blocks, (3) the block's kept rows mark the later columns they suppress
-  // (one 64-column word per wave and step).  n^2 / 2 pair tests by one workgroup: 50 candidates 3 us, 1000 ~100 us.
+  // (one 64-column word per wave and step).  n^2 / 2 pair tests by ONE workgroup: 50 candidates 3 us, 1000 ~100 us, 4096 would be
+  // ~1.5 ms -- a deliberate trade for the 81-class detection heads this path serves (segments of tens of candidates); a model with a
+  // handful of classes, a very low score threshold or collect_top_n >> 2000 makes a class segment the critical path of the launch
+  // (timing guard: tests/test_hip_fpn_det_mask.py::test_postprocess_crowded_classes_vs_oracle, R = 1500 x 3 classes).
   {
     uint64_t* removed = reinterpret_cast<uint64_t*>(rank_of_q + kNmsLdsCap);                         // [(R + 63) / 64]
     __shared__ uint32_t diag_s[kDetThreads / 64][64];

@@ -202,7 +202,9 @@ def bias_act_(x, bias=None, residual=None, relu=True, residual_up2=False):
 
 def roi_align_set_exact(exact=True):
     """Process-wide switch (dtc_roi_align_set_exact): True (default) = bit-identical to the reference; False = the C4 (adaptive
-    sampling, single level) kernel may merge taps -- the same sums in exact arithmetic, <= 1e-5 from the reference in float32."""
+    sampling, single level) kernel may merge taps -- the same sums in exact arithmetic, <= 1e-5 from the reference in float32.
+    Read by the host at LAUNCH time: a hipGraph keeps the mode it was captured with; shared by all threads / streams of the process
+    (include/detectorch_hip.h)."""
     lib().dtc_roi_align_set_exact(1 if exact else 0)
 
 

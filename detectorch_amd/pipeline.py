@@ -207,19 +207,32 @@ class FpnRegionPath:
         fb = sum(f.numel() * f.element_size() for f in self.feats)
         return fb + self.B * self.top_n * 5 * 4 + self.box_feats.numel() * self.box_feats.element_size()
 
-    def results(self):
-        """Host copy of the detections of the last step: list of dict(boxes, scores, classes) per image."""
+    def results(self, on_overflow="raise"):
+        """Host copy of the detections of the last step: list of dict(boxes, scores, classes) per image.
+
+        The reference keeps every detection that ties at the image threshold (result_utils.py:159-163); the fixed-shape rows hold
+        max_out of them.  More ties than rows must not disappear silently: on_overflow="raise" (default: an evaluation run must stop),
+        or "truncate" for a serving loop that must not abort on a rare tie -- the first max_out rows (class-major order) are returned,
+        a warning is issued and the image's dict carries truncated=True and n_detections = the true count."""
+        if on_overflow not in ("raise", "truncate"):
+            raise ValueError("on_overflow must be 'raise' or 'truncate'")
         cnt = self.det_count.cpu().numpy()
         dets = self.dets.cpu().numpy()
         out = []
         for b in range(self.B):
-            if int(cnt[b]) > self.max_out:
-                # the reference keeps every detection that ties at the image threshold (result_utils.py:159-163); the fixed-shape
-                # rows hold max_out of them: more ties than that must not disappear silently
-                raise RuntimeError("image %d has %d detections (ties at the image threshold) but max_out = %d rows: raise max_out"
-                                   % (b, int(cnt[b]), self.max_out))
-            n = int(cnt[b])
-            out.append(dict(boxes=dets[b, :n, :4].copy(), scores=dets[b, :n, 4].copy(), classes=dets[b, :n, 5].astype(np.int32)))
+            n, over = int(cnt[b]), int(cnt[b]) > self.max_out
+            if over:
+                msg = ("image %d has %d detections (ties at the image threshold) but max_out = %d rows: raise max_out"
+                       % (b, n, self.max_out))
+                if on_overflow == "raise":
+                    raise RuntimeError(msg)
+                import warnings
+                warnings.warn(msg + " -- truncated", RuntimeWarning)
+                n = self.max_out
+            d = dict(boxes=dets[b, :n, :4].copy(), scores=dets[b, :n, 4].copy(), classes=dets[b, :n, 5].astype(np.int32))
+            if over:
+                d["truncated"], d["n_detections"] = True, int(cnt[b])
+            out.append(d)
         return out
 
 

@@ -201,7 +201,7 @@ def segm_results(cls_boxes, masks, ref_boxes, im_h, im_w, num_classes=81, M=14, 
 
 
 def assemble_results(dets, det_count, im_sizes=None, rle_str=None, rle_len=None, num_classes=81, all_boxes=None,
-                     all_segms=None, first_image=0):
+                     all_segms=None, first_image=0, on_overflow="raise"):
     """all_boxes / all_segms (result_utils.py:32-60) from the fixed-shape outputs of the batched path.
 
       dets [N, max_out, 6] = (x1,y1,x2,y2,score,class) class-major per image, det_count [N]   (dtc_postprocess_detections,
@@ -211,7 +211,10 @@ def assemble_results(dets, det_count, im_sizes=None, rle_str=None, rle_len=None,
     all_boxes[cls][image] = [k,5] array (x1,y1,x2,y2,score); all_segms[cls][image] = list of COCO RLE dicts in 1:1
     correspondence -- exactly what `extend_results(i, all_boxes, cls_boxes_i)` / `extend_results(i, all_segms, cls_segms_i)`
     leave behind image by image in the reference's eval loop.  Pass all_boxes / all_segms / first_image to fill a slice of
-    existing lists (e.g. the shard of one rank)."""
+    existing lists (e.g. the shard of one rank).  on_overflow: an image with more detections (ties at the image threshold) than the
+    max_out fixed rows raises ("raise", default) or keeps the first max_out rows with a RuntimeWarning ("truncate")."""
+    if on_overflow not in ("raise", "truncate"):
+        raise ValueError("on_overflow must be 'raise' or 'truncate'")
     dets, det_count = to_np(dets), to_np(det_count).reshape(-1)
     N, max_out = dets.shape[0], dets.shape[1]
     if all_boxes is None:
@@ -222,8 +225,12 @@ def assemble_results(dets, det_count, im_sizes=None, rle_str=None, rle_len=None,
         im_sizes = to_np(im_sizes).reshape(N, -1)
     for i in range(N):
         if int(det_count[i]) > max_out:      # ties at the image threshold beyond the fixed rows (result_utils.py:159-163 keeps them all)
-            raise RuntimeError("image %d: %d detections but only %d rows were kept: raise the path's max_out" % (first_image + i, int(det_count[i]), max_out))
-        n = int(det_count[i])
+            msg = "image %d: %d detections but only %d rows were kept: raise the path's max_out" % (first_image + i, int(det_count[i]), max_out)
+            if on_overflow == "raise":
+                raise RuntimeError(msg)
+            import warnings
+            warnings.warn(msg + " -- truncated", RuntimeWarning)
+        n = min(int(det_count[i]), max_out)
         d = dets[i, :n]
         cls = d[:, 5].astype(np.int64)
         for j in range(1, num_classes):

@@ -90,7 +90,10 @@ int dtc_roi_align_forward_packed(const dtc_feat_level* levels, int n_levels, int
  * take that kernel ignore the workspace (NULL is allowed: then this IS dtc_roi_align_forward_packed). */
 size_t dtc_roi_align_workspace_bytes(int n_rois);
 
-/* Exactness switch of the adaptive-sampling (sampling_ratio <= 0) single-level path, process-wide, read at launch time.
+/* Exactness switch of the adaptive-sampling (sampling_ratio <= 0) single-level path.  SEMANTICS: one process-wide value shared by
+ * every thread and stream, read by the HOST at launch time and baked into the launch: a launch captured into a hipGraph keeps the
+ * mode it was captured with (toggling later does not change replays), and two threads that want different modes must serialise
+ * their launches around the switch themselves.  Leave it at 1 unless the whole process opts into the approximate mode.
  * exact = 1 (default): the reference's float32 operations in the reference's order (roi_align_cpu_loop.cpp:203-216): bit-identical.
  * exact = 0: with a workspace (dtc_roi_align_forward_packed_ws) the kernel may merge the gh x gw samples x 4 taps of a bin into
  * (gh + 1) x (gw + 1) taps with separable weight sums: the same sum in exact arithmetic, <= 1e-5 away in float32 on O(1) features
@@ -208,7 +211,10 @@ int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_scores, co
  * Outputs: dets [B,max_out,6] = (x1,y1,x2,y2,score,class) ordered by class then by roi index (== np.vstack(cls_boxes),
  * :165); det_roi int32 [B,max_out] source roi; det_rois_scaled [B,max_out,4] = boxes * scaling_factor (nullable; the
  * rois of the mask branch, eval_mask_FPN.ipynb:249); det_count int32 [B] = true number (can exceed max_det on score
- * ties like the reference, :161; rows beyond max_out are dropped -- compare det_count with max_out). R <= 4096. */
+ * ties like the reference, :161; rows beyond max_out are dropped -- compare det_count with max_out). R <= 4096.
+ * Cost model: the per-class NMS of a (class, image) segment runs inside ONE workgroup, n^2 / 2 pair tests for n candidates above the
+ * score threshold -- microseconds for the 81-class heads this serves (tens of candidates per class), ~100 us at n = 1000, ~1.5 ms at
+ * n = 4096: few-class models with low thresholds should expect the largest class segment to set the launch time. */
 size_t dtc_postprocess_detections_workspace_bytes(int batch, int max_rois, int n_cls);
 int dtc_postprocess_detections(const float* rois5, const int32_t* n_rois, const float* cls_score, const float* bbox_pred,
                                const float* scaling_factor, const float* im_size, int batch, int max_rois, int n_cls,

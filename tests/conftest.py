@@ -15,6 +15,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "offscope: GPU tests of code OUTSIDE the hot path of SURVEY.md section 8 (the frozen backbone epilogue); "
+                                       "additive to `gpu`: -m \"gpu and not offscope\" counts the hot-path tests only")
 
 
 def golden(name):

@@ -228,6 +228,19 @@ def test_postprocess_crowded_classes_vs_oracle(hip, oracle, R, n_cls):
         assert c == rd.shape[0] and 0 < c < n * (n_cls - 1)              # something kept, something suppressed
         assert np.array_equal(dets[b, :c].cpu().numpy(), rd[:c])
         assert np.array_equal(roi[b, :c].cpu().numpy(), rr[:c])
+    if R == 1500:
+        # timing guard: a crowded class segment is ONE workgroup's n^2 / 2 pair tests -- ~1500 candidates cost a few
+        # hundred microseconds (documented in csrc/detections.hip and include/detectorch_hip.h); a regression to milliseconds fails here
+        args = (cu(rois5), cu(n_rois), cu(cls), cu(dl), cu(sf), cu(im))
+        for _ in range(2):
+            hip.postprocess_detections(*args, max_det=0, max_out=cap)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            hip.postprocess_detections(*args, max_det=0, max_out=cap)
+        e1.record()
+        torch.cuda.synchronize()
+        assert e0.elapsed_time(e1) / 5 < 3.0, "postprocess of 2 x 1500 RoIs x 3 classes took %.2f ms per call" % (e0.elapsed_time(e1) / 5)
 
 
 # ---------------------------------------------------------------- A9 ------------------------------------------------

@@ -242,3 +242,30 @@ def test_channels_last_maps_equal_nchw_maps(oracle, use_graph):
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert int(res[0][4].min()) > 0 and float(res[0][5].abs().sum()) > 0
+
+
+def test_more_ties_than_rows_raise_or_truncate(oracle):
+    """More detections than the fixed max_out rows (ties at the image threshold, result_utils.py:159-163) never disappear silently:
+    results() / assemble_results raise by default; on_overflow="truncate" keeps the first max_out rows, warns and flags the image."""
+    from detectorch_amd.pipeline import FpnRegionPath, synthetic_batch
+    from detectorch_amd.utils import result_utils
+    dev = torch.device("cuda", 0)
+    path = FpnRegionPath(2, dev, channels=8, max_out=104)
+    path.bind(*synthetic_batch(2, dev, seed=3000, channels=8, max_out=104))
+    path.step(use_graph=False)
+    torch.cuda.synchronize()
+    ok = path.results()
+    assert len(ok) == 2 and "truncated" not in ok[0]
+    path.det_count[1] = path.max_out + 5             # what the kernel reports when 109 detections tie into the top 100
+    with pytest.raises(RuntimeError):
+        path.results()
+    with pytest.raises(RuntimeError):
+        result_utils.assemble_results(path.dets, path.det_count)
+    with pytest.warns(RuntimeWarning):
+        got = path.results(on_overflow="truncate")
+    assert got[1]["truncated"] and got[1]["n_detections"] == path.max_out + 5 and got[1]["boxes"].shape[0] == path.max_out
+    assert np.array_equal(got[0]["boxes"], ok[0]["boxes"])
+    with pytest.warns(RuntimeWarning):
+        boxes, _ = result_utils.assemble_results(path.dets, path.det_count, on_overflow="truncate")
+    # (the rows past the true count are zero rows of class 0 here: the count was faked)
+    assert sum(len(boxes[j][1]) for j in range(1, 81)) == int((path.dets[1, :, 5] >= 1).sum())

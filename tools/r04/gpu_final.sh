@@ -39,7 +39,7 @@ t["pure_load_ceilings_recorded"] = {"what": "tools/micro/l1_fill_ceiling.hip on 
 json.dump(t, open("profiles/roialign_traffic.json", "w"), indent=1)
 json.dump(t, open("$O/roialign_traffic.json", "w"), indent=1)
 PY
-timeout 900 bash tools/r04/gpu19.sh > $O/nhwc16_counters.log 2>&1      # L1 / L2 / SQ counters of the grouped 16-bit channels_last kernel -> gpurun_out/r04n/counters.json
+timeout 900 bash tools/r04/runs/gpu19.sh > $O/nhwc16_counters.log 2>&1      # L1 / L2 / SQ counters of the grouped 16-bit channels_last kernel -> gpurun_out/r04n/counters.json
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 900 python bench.py --workload cfg5 --cpu-images 2 > $O/bench_cfg5.json 2> $O/bench_cfg5.err
 timeout 900 python bench.py --workload cfg5 --nchw --cpu-images 2 > $O/bench_cfg5_nchw.json 2> $O/bench_cfg5_nchw.err

@@ -2,7 +2,7 @@
 # Round 4, measurement set 1 (VERDICT r03 "Next round" 1a): the L2-resident L1-fill ceiling, and TCC / EA / TCP counters of
 #   (i) the shipped NCHW box-head launch, (ii) the 1-image x 8000-RoI control, (iii) roi_align_fwd_nhwc_lds fp32 on the bench inputs,
 # plus the dispatch-order variants of the cluster kernel (channel-block-major XCD walk, clock-phased passes) WITH their L2 counters.
-#   bash tools/r04/gpu1.sh   (GPU box, repo root)  -> gpurun_out/r04a/
+#   bash tools/r04/runs/gpu1.sh   (GPU box, repo root)  -> gpurun_out/r04a/
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r04a; mkdir -p $O
