@@ -883,7 +883,7 @@ static int roi_align_dispatch(const dtc_feat_level* levels, int n_levels, int ch
   // ~300-pixel window: 2.5 taps per pixel, measured 0.50 vs 0.65 ms); with 14x14 bins (10 taps per pixel) staging the window
   // in LDS wins (0.21 vs 0.37 ms), and the LDS kernel stages channels_last windows with 16-byte loads too.
   const bool few_taps = sampling_ratio > 0 && (long long)pooled_h * pooled_w * sampling_ratio * sampling_ratio <= 256;
-  // 16-bit channels_last maps (float32 ones with DTC_RA_NHWC_DIRECT32=1), 2 x 2 samples: 16-byte lanes, the bins of several RoIs flattened over a workgroup (roi_align_nhwc16.hip)
+  // 16-bit channels_last maps, and float32 ones with <= 64 bins (DTC_RA_NHWC_DIRECT32=0: the LDS-DMA kernels instead), 2 x 2 samples: 16-byte lanes, the bins of several RoIs flattened over a workgroup (roi_align_nhwc16.hip)
   if (all_nhwc && !cfg.general && cfg.nhwc_direct && dtc::roi_align_nhwc16_supported(p, in_dtype, out_dtype))
     return dtc::launch_roi_align_nhwc16(p, in_dtype, out_dtype, s);
   // channels_last, sampling_ratio 2, <= 64 bins: window staged with LDS-DMA, conflict-free tap reads (roi_align_nhwc.hip)

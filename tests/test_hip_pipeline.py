@@ -223,9 +223,11 @@ def test_c4_region_path_true_channel_count(oracle, pooled):
 
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_channels_last_maps_equal_nchw_maps(oracle, use_graph):
-    """The same inputs with channels_last float32 feature maps (C = 128: two 64-channel items per RoI): box-head features through
-    roi_align_fwd_nhwc_lds, mask-branch features (14 x 14 bins, packed descriptors with padding rows) through the pipelined kernel
-    roi_align_fwd_nhwc_pipe -- every result equal, bit for bit, to the NCHW path's (which the oracle-chain tests pin)."""
+    """The same inputs with channels_last float32 feature maps (C = 128): box-head features through the grouped direct kernel
+    (roi_align_fwd_nhwc16<float>: the default for float32 launches with <= 64 bins since round 4; the LDS-DMA kernel it displaced
+    runs in the DTC_RA_NHWC_DIRECT32=0 child processes of test_hip_roi_align.py), mask-branch features (14 x 14 bins, packed
+    descriptors with padding rows) through the pipelined kernel roi_align_fwd_nhwc_pipe -- every result equal, bit for bit, to the
+    NCHW path's (which the oracle-chain tests pin)."""
     from detectorch_amd.pipeline import FpnRegionPath, synthetic_batch
     dev = torch.device("cuda", 0)
     B, C = 3, 128
