@@ -344,7 +344,7 @@ __device__ __forceinline__ void run_passes(Stager& st, LdsGeom& G, const dtc_fea
     } else if (sizeof(TOut) == 4 && ((reinterpret_cast<uintptr_t>(og) & 15) == 0)) {
       const int n4 = n_out >> 2;
       for (int i = tid; i < n4; i += kRoiAlignThreads)
-        reinterpret_cast<float4*>(og)[i] = reinterpret_cast<const float4*>(G.slab)[i];
+        store_stream16(reinterpret_cast<float4*>(og) + i, reinterpret_cast<const float4*>(G.slab)[i]);
       for (int i = (n4 << 2) + tid; i < n_out; i += kRoiAlignThreads) og[i] = from_f32<TOut>(G.slab[i]);
     } else {
       for (int i = tid; i < n_out; i += kRoiAlignThreads) og[i] = from_f32<TOut>(G.slab[i]);
@@ -558,7 +558,7 @@ __device__ __forceinline__ void store_slab_vec(TOut* out, const float* slab, int
   if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {
     if constexpr (sizeof(TOut) == 4) {
       const int n4 = n_out >> 2;
-      for (int i = tid; i < n4; i += THREADS) reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(slab)[i];
+      for (int i = tid; i < n4; i += THREADS) store_stream16(reinterpret_cast<float4*>(out) + i, reinterpret_cast<const float4*>(slab)[i]);
       for (int i = (n4 << 2) + tid; i < n_out; i += THREADS) out[i] = from_f32<TOut>(slab[i]);
     } else {
       const int n8 = n_out >> 3;
@@ -571,7 +571,7 @@ __device__ __forceinline__ void store_slab_vec(TOut* out, const float* slab, int
           const TOut lo = from_f32<TOut>(v[2 * k]), hi = from_f32<TOut>(v[2 * k + 1]);
           w[k] = (uint32_t)*reinterpret_cast<const uint16_t*>(&lo) | ((uint32_t)*reinterpret_cast<const uint16_t*>(&hi) << 16);
         }
-        reinterpret_cast<uint4*>(out)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        store_stream16(reinterpret_cast<uint4*>(out) + i, w[0], w[1], w[2], w[3]);
       }
       for (int i = (n8 << 3) + tid; i < n_out; i += THREADS) out[i] = from_f32<TOut>(slab[i]);
     }

@@ -70,18 +70,16 @@ template <> struct NlLane<bf16_t> {
 };
 
 template <typename TOut> __device__ __forceinline__ void nl_store4(TOut* d, float4 v);
-template <> __device__ __forceinline__ void nl_store4<float>(float* d, float4 v) { *reinterpret_cast<float4*>(d) = v; }
+template <> __device__ __forceinline__ void nl_store4<float>(float* d, float4 v) { store_stream16(d, v); }     // streaming stores: dtc_common.h
 template <> __device__ __forceinline__ void nl_store4<__half>(__half* d, float4 v) {
   const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
-  uint2 r; r.x = *reinterpret_cast<const uint32_t*>(&a); r.y = *reinterpret_cast<const uint32_t*>(&b);
-  *reinterpret_cast<uint2*>(d) = r;
+  store_stream8(d, *reinterpret_cast<const uint32_t*>(&a), *reinterpret_cast<const uint32_t*>(&b));
 }
 template <> __device__ __forceinline__ void nl_store4<bf16_t>(bf16_t* d, float4 v) {
-  uint2 r;
-  r.x = (uint32_t)from_f32<bf16_t>(v.x).bits | ((uint32_t)from_f32<bf16_t>(v.y).bits << 16);
-  r.y = (uint32_t)from_f32<bf16_t>(v.z).bits | ((uint32_t)from_f32<bf16_t>(v.w).bits << 16);
-  *reinterpret_cast<uint2*>(d) = r;
+  store_stream8(d, (uint32_t)from_f32<bf16_t>(v.x).bits | ((uint32_t)from_f32<bf16_t>(v.y).bits << 16),
+                (uint32_t)from_f32<bf16_t>(v.z).bits | ((uint32_t)from_f32<bf16_t>(v.w).bits << 16));
 }
+
 
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(kNlThreads) void roi_align_fwd_nhwc_lds(RoiAlignParams p, int img_pixels) {

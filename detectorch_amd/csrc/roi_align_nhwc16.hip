@@ -168,7 +168,8 @@ __global__ __launch_bounds__(kN16Threads) void roi_align_fwd_nhwc16(RoiAlignPara
   for (int i = tid; i < ng * n16; i += kN16Threads) {
     const int k = i / n16, j = i - k * n16;
     TOut* out = reinterpret_cast<TOut*>(p.out) + ((size_t)rinfo[k].r * p.channels + c0) * bins;
-    reinterpret_cast<uint4*>(out)[j] = reinterpret_cast<const uint4*>(slab + (size_t)k * CB * bins)[j];
+    const uint4 v = reinterpret_cast<const uint4*>(slab + (size_t)k * CB * bins)[j];
+    store_stream16(reinterpret_cast<uint4*>(out) + j, v.x, v.y, v.z, v.w);
   }
 }
 
