@@ -10,7 +10,7 @@ path = FpnRegionPath(8, dev, max_out=104); path.bind(*synthetic_batch(8, dev, se
 for _ in range(3): path.step(use_graph=False)
 torch.cuda.synchronize()
 L = hip.lib()
-names = {"proposals": {0: "rpn_hist<0>", 1: "rpn_hist<1>", 2: "rpn_compact", 3: "rpn_sort_decode"}, "detections": {0: "det_candidates", 1: "det_finalize"},
+names = {"proposals": {0: "rpn_hist<0>", 1: "rpn_hist<1>", 2: "rpn_compact", 3: "rpn_sort"}, "detections": {0: "det_candidates", 1: "det_finalize"},
          "nms": {0: "nms_reduce_lds"}, "fpn": {0: "fpn_collect_fast (box)", 1: "fpn_collect_fast (mask)"}, "mask_paste": {0: "mask_paste", 1: "mask_paste (helpers)"}}
 for f, ks in names.items():
     buf = np.zeros((4, 64, 24), np.uint64)
