@@ -9,7 +9,7 @@ for f in sorted(glob.glob(O + "/g*_counter_collection.csv")):
             g = int(r["Grid_Size"])
             acc[g][r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur[g][(f, r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-g = max(acc)
+g = max(acc, key=lambda k: (len(next(iter(acc[k].values()))), k))      # the launch that was repeated (ties: the larger grid)
 avg = {k: sum(v[1:]) / max(1, len(v) - 1) for k, v in acc[g].items()}
 avg["grid"] = g
 avg["kernel"] = [r["Kernel_Name"][:60] for r in csv.DictReader(open(sorted(glob.glob(O + "/g1_counter_collection.csv"))[0])) if "roi_align" in r["Kernel_Name"] and int(r["Grid_Size"]) == g][0]
