@@ -103,6 +103,85 @@ __device__ __forceinline__ void block_bitonic_sort(uint64_t* keys, int n_pow2) {
   else __builtin_trap();        // more than 16 keys per thread: no instantiation sorts that (callers bound n_pow2 on the host)
 }
 
+// Stable LSD radix sort of n 64-bit keys (ascending) for LONG lists -- the 6000 + candidate keys of a C4 RPN segment, where the bitonic
+// network above needs 91 steps over 8192 padded keys (85 us in one workgroup).  8-bit digits; `digit_mask` bit d set = digit d (key bits
+// [8d, 8d + 8)) can differ between keys (the caller knows how many index bits are in use: the all-zero digits are skipped).  Two LDS key
+// buffers (src = a on entry; returns the buffer that holds the sorted keys) + cnt[(THREADS / 64) * 256] counters.
+// Wave w owns the contiguous positions [w * 64 * E, (w + 1) * 64 * E) of the current order, lane l its elements w * 64 * E + 64 e + l: inside a
+// wave the order is (e, lane), so the rank of an element among the wave's equal digits = (equal digits of the wave's earlier rounds: a
+// running per-wave counter) + (equal digits in lower lanes of this round: 8 ballots); across waves one exclusive scan per digit.
+// Every thread of the block must call; n <= THREADS * E.
+template <int THREADS, int E>
+__device__ __forceinline__ uint64_t* block_radix_sort_u64(uint64_t* a, uint64_t* b, uint32_t* cnt, uint32_t* dig_base, int n, uint32_t digit_mask) {
+  constexpr int NW = THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  uint64_t* src = a;
+  uint64_t* dst = b;
+  uint32_t* wc = cnt + w * 256;
+  __syncthreads();                                         // keys were written by arbitrary threads before the call
+  for (int d = 0; d < 8; d++) {
+    if (!((digit_mask >> d) & 1u)) continue;               // uniform
+    const int shift = 8 * d;
+    for (int i = tid; i < NW * 256; i += THREADS) cnt[i] = 0;
+    __syncthreads();
+    uint64_t key[E];
+    uint32_t rank[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int pos = w * 64 * E + 64 * e + lane;
+      const bool valid = pos < n;
+      key[e] = valid ? src[pos] : ~0ull;
+      const uint32_t dg = (uint32_t)(key[e] >> shift) & 255u;
+      uint64_t peers = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; bit++) {
+        const bool one = (dg >> bit) & 1u;
+        const uint64_t m = __ballot(one);
+        peers &= one ? m : ~m;
+      }
+      const int leader = __builtin_ctzll(peers | (1ull << 63));     // (peers != 0 for a valid lane: it contains the lane itself)
+      const uint32_t below = (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1ull));
+      uint32_t prior = 0;
+      if (valid && lane == leader) { prior = wc[dg]; wc[dg] = prior + (uint32_t)__builtin_popcountll(peers); }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the wave's counter updates retire in order, round by round
+      prior = (uint32_t)__shfl((int)prior, leader, 64);
+      rank[e] = prior + below;
+    }
+    __syncthreads();
+    // per digit: exclusive scan of the wave counts, digit totals; then the exclusive scan of the 256 totals (wave 0)
+    if (tid < 256) {
+      uint32_t tot = 0;
+#pragma unroll
+      for (int ww = 0; ww < NW; ww++) { const uint32_t c = cnt[ww * 256 + tid]; cnt[ww * 256 + tid] = tot; tot += c; }
+      dig_base[tid] = tot;
+    }
+    __syncthreads();
+    if (w == 0) {
+      uint32_t v4[4], sum = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { v4[q] = dig_base[4 * lane + q]; sum += v4[q]; }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= off) incl += o; }
+      uint32_t run = incl - sum;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { dig_base[4 * lane + q] = run; run += v4[q]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int pos = w * 64 * E + 64 * e + lane;
+      if (pos < n) {
+        const uint32_t dg = (uint32_t)(key[e] >> shift) & 255u;
+        dst[dig_base[dg] + wc[dg] + rank[e]] = key[e];
+      }
+    }
+    __syncthreads();
+    uint64_t* t = src; src = dst; dst = t;
+  }
+  return src;
+}
+
 __host__ __device__ __forceinline__ int next_pow2(int n) {
   int p = 2;
   while (p < n) p <<= 1;

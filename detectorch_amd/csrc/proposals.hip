@@ -330,13 +330,25 @@ __global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_kernel(RpnParams 
   }
   __syncthreads();
   DTC_PT(3, seg, 1);
-  block_bitonic_sort<kSortDecodeThreads>(keys, np2);
+  const uint64_t* sorted = keys;
+  if (np2 > 2048 && sort_cap <= 8192) {
+    // long segments (C4: 6000 ranks; up to 8192 keys -- beyond that the two key buffers do not fit LDS: bitonic): LSD radix sort over the score word and the index bits in use, 6 passes instead of the 91
+    // compare-exchange steps of an 8192-key bitonic network (85 -> ~20 us)
+    uint64_t* keys2 = keys + sort_cap;
+    uint32_t* rcnt = reinterpret_cast<uint32_t*>(keys2 + sort_cap);
+    const int idx_bits = 32 - __builtin_clz((unsigned)max(L.N - 1, 1));
+    uint32_t dmask = 0xf0u;                                  // the four score digits
+    for (int d = 0; d < 4; d++) if (8 * d < idx_bits) dmask |= 1u << d;
+    sorted = block_radix_sort_u64<kSortDecodeThreads, 8>(keys, keys2, rcnt, hsel, total, dmask);
+  } else {
+    block_bitonic_sort<kSortDecodeThreads>(keys, np2);
+  }
   DTC_PT(3, seg, 2);
 
   // the first K keys are the answer: hand them to rpn_decode (a segment's 6000 ranks are decoded by 24 workgroups, not by this one)
   const int n_rank = min(K, total);
   uint64_t* sk = p.sorted_keys + (size_t)seg * p.k_stride;
-  for (int k = tid; k < n_rank; k += kSortDecodeThreads) sk[k] = keys[k];
+  for (int k = tid; k < n_rank; k += kSortDecodeThreads) sk[k] = sorted[k];
   if (tid == 0) p.n_rank[seg] = n_rank;
   DTC_PT(3, seg, 3);
 }
@@ -524,9 +536,11 @@ DTC_API int dtc_rpn_topk_decode(const dtc_rpn_level* levels, int n_levels, int b
   hipLaunchKernelGGL(dtc::rpn_compact_kernel, grid, blk, 0, s, p);
   DTC_CHECK_LAUNCH();
   const int sort_cap = dtc::next_pow2(plan.k_stride) <= 1024 ? 2048 : dtc::next_pow2(plan.k_stride);
-  const size_t smem = (size_t)sort_cap * sizeof(uint64_t);
+  // sort_cap keys; long segments (radix sort): a second key buffer + 16 x 256 per-wave digit counters
+  const size_t smem = (sort_cap > 2048 && sort_cap <= 8192) ? (size_t)sort_cap * sizeof(uint64_t) * 2 + (dtc::kSortDecodeThreads / 64) * 256 * sizeof(uint32_t)
+                                      : (size_t)sort_cap * sizeof(uint64_t);
   if (smem > 32 * 1024) {   // static __shared__ of the kernel comes on top: raise the limit well before dynamic + static reaches 64 KB
-    DTC_RAISE_LDS_ONCE(dtc::rpn_sort_kernel, 144 * 1024);
+    DTC_RAISE_LDS_ONCE(dtc::rpn_sort_kernel, 150 * 1024);
   }
   hipLaunchKernelGGL(dtc::rpn_sort_kernel, dim3(plan.n_seg), dim3(dtc::kSortDecodeThreads), smem, s, p, sort_cap);
   hipLaunchKernelGGL(dtc::rpn_decode_kernel, dim3(plan.dec_blocks, plan.n_seg), dim3(dtc::kDecodeThreads), 0, s, p);
