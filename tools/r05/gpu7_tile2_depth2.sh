@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS commit 1e29752 plus the depth-2 variant described in tools/r05/README.md 4c (not kept); the record of the commands
 # round 5, call 7: tile2 with the loads two passes ahead (8 pieces in flight, 52 KB, 3 workgroups / CU) against the shipped kernel
 DTC_RA_TILE2=1 DTC_RA_TILE2_DEPTH=2 python -m pytest tests/test_hip_roi_align.py -x -q -m gpu -k "window_shapes or edge_cases or full_channel or (real_shape and fp32 and nchw) or golden" 2>&1 | tail -2
 for rep in 1 2; do
