@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS the reverted experiment code (a global progress table + pick() in tile_passes: tools/r05/README.md 4b); kept as the record of the commands
 # round 5, call 4: follow-the-predecessor pass order (DTC_RA_TILE_FOLLOW=1) against the shipped order: parity, times, L2 counters
 DTC_RA_TILE_FOLLOW=1 python -m pytest tests/test_hip_roi_align.py -x -q -m gpu -k "window_shapes or edge_cases or full_channel or (real_shape and fp32 and nchw) or golden" 2>&1 | tail -2
 for rep in 1 2; do for f in 0 1; do
