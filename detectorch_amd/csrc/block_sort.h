@@ -118,6 +118,7 @@ __device__ __forceinline__ uint64_t* block_radix_sort_u64(uint64_t* a, uint64_t*
   uint64_t* src = a;
   uint64_t* dst = b;
   uint32_t* wc = cnt + w * 256;
+  if (n > THREADS * E) __builtin_trap();                   // like the bitonic sort: callers bound n on the host
   __syncthreads();                                         // keys were written by arbitrary threads before the call
   for (int d = 0; d < 8; d++) {
     if (!((digit_mask >> d) & 1u)) continue;               // uniform

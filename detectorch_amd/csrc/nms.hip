@@ -228,7 +228,10 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const uint64_t* __restri
                                                         int32_t* __restrict__ next_counts) {
   __shared__ uint64_t removed[256];            // one bit per box, up to 16384 boxes
   const int s = blockIdx.x, lane = threadIdx.x, rg = lane >> 4, cbl = lane & 15;
-  if (counts && counts[s] < 0) return;         // a segment that is already reduced (the first phase below finished it): keep / keep_count stay
+  if (counts && counts[s] < 0) {               // a segment that is already reduced (the first phase below finished it, or the CALLER says so): keep / keep_count stay
+    if (next_counts && lane == 0) next_counts[s] = -1;   // ... in the second phase of a keep[:max_keep] call too (it runs on next_counts)
+    return;
+  }
   const int n_full = counts ? min(counts[s], n_stride) : n_stride;
   const int n = min(n_full, n_cap);
   const int ncb = (n + 63) >> 6;

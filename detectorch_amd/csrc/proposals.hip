@@ -251,6 +251,18 @@ __device__ __forceinline__ void decode_box(float ax1, float ay1, float ax2, floa
 }
 
 constexpr int kSortDecodeThreads = 1024;
+constexpr int kRadixKeysPerThread = 8;
+// ONE place that says when rpn_sort takes the LSD radix sort and how much dynamic LDS it needs (host launch + kernel branch):
+// more than 2048 keys to order and a key capacity the two key buffers + 16 x 256 per-wave digit counters fit LDS with
+// (8192 keys: 2 x 64 KB + 16 KB = 144 KB dynamic + ~8.3 KB static of the 160 KB).
+__host__ __device__ constexpr bool rpn_sort_radix_capable(int sort_cap) {
+  return sort_cap > 2048 && sort_cap <= kSortDecodeThreads * kRadixKeysPerThread;
+}
+__host__ __device__ constexpr size_t rpn_sort_lds_bytes(int sort_cap) {
+  return rpn_sort_radix_capable(sort_cap)
+             ? (size_t)sort_cap * sizeof(uint64_t) * 2 + (size_t)(kSortDecodeThreads / 64) * 256 * sizeof(uint32_t)
+             : (size_t)sort_cap * sizeof(uint64_t);
+}
 
 // Ascending digit select inside the workgroup: smallest digit d with  count(digits <= d) >= rem.  hist[nbins] in LDS,
 // nbins <= 2048.  Returns d in sh[0] and the rank left inside digit d in sh[1].  (select_digit picks from the top: feed
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_kernel(RpnParams 
   __syncthreads();
   DTC_PT(3, seg, 1);
   const uint64_t* sorted = keys;
-  if (np2 > 2048 && sort_cap <= 8192) {
+  if (np2 > 2048 && rpn_sort_radix_capable(sort_cap)) {
     // long segments (C4: 6000 ranks; up to 8192 keys -- beyond that the two key buffers do not fit LDS: bitonic): LSD radix sort over the score word and the index bits in use, 6 passes instead of the 91
     // compare-exchange steps of an 8192-key bitonic network (85 -> ~20 us)
     uint64_t* keys2 = keys + sort_cap;
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(kSortDecodeThreads) void rpn_sort_kernel(RpnParams 
     const int idx_bits = 32 - __builtin_clz((unsigned)max(L.N - 1, 1));
     uint32_t dmask = 0xf0u;                                  // the four score digits
     for (int d = 0; d < 4; d++) if (8 * d < idx_bits) dmask |= 1u << d;
-    sorted = block_radix_sort_u64<kSortDecodeThreads, 8>(keys, keys2, rcnt, hsel, total, dmask);
+    sorted = block_radix_sort_u64<kSortDecodeThreads, kRadixKeysPerThread>(keys, keys2, rcnt, hsel, total, dmask);
   } else {
     block_bitonic_sort<kSortDecodeThreads>(keys, np2);
   }
@@ -370,6 +382,9 @@ __global__ __launch_bounds__(kDecodeThreads) void rpn_decode_kernel(RpnParams p)
   if (tid == 0) sh_blk = (int)atomicAdd(&p.ticket[seg], 1u);
   __syncthreads();
   const int blk = sh_blk;
+  // tickets past the block count: the workspace is shared with another in-flight call (include/detectorch_hip.h forbids it) or was
+  // not cleared for this launch -- leave instead of writing block counts out of bounds (uniform: after the barrier)
+  if (blk >= p.dec_blocks) return;
   const int n_rank = p.n_rank[seg];
   const uint64_t* sk = p.sorted_keys + (size_t)seg * p.k_stride;
   const float* sc = L.cls + (size_t)b * L.N;
@@ -537,12 +552,12 @@ DTC_API int dtc_rpn_topk_decode(const dtc_rpn_level* levels, int n_levels, int b
   DTC_CHECK_LAUNCH();
   const int sort_cap = dtc::next_pow2(plan.k_stride) <= 1024 ? 2048 : dtc::next_pow2(plan.k_stride);
   // sort_cap keys; long segments (radix sort): a second key buffer + 16 x 256 per-wave digit counters
-  const size_t smem = (sort_cap > 2048 && sort_cap <= 8192) ? (size_t)sort_cap * sizeof(uint64_t) * 2 + (dtc::kSortDecodeThreads / 64) * 256 * sizeof(uint32_t)
-                                      : (size_t)sort_cap * sizeof(uint64_t);
+  const size_t smem = dtc::rpn_sort_lds_bytes(sort_cap);
   if (smem > 32 * 1024) {   // static __shared__ of the kernel comes on top: raise the limit well before dynamic + static reaches 64 KB
     DTC_RAISE_LDS_ONCE(dtc::rpn_sort_kernel, 150 * 1024);
   }
   hipLaunchKernelGGL(dtc::rpn_sort_kernel, dim3(plan.n_seg), dim3(dtc::kSortDecodeThreads), smem, s, p, sort_cap);
+  DTC_CHECK_LAUNCH();        // (a failed sort launch -- LDS over the limit -- must not be masked by the decode launch that follows)
   hipLaunchKernelGGL(dtc::rpn_decode_kernel, dim3(plan.dec_blocks, plan.n_seg), dim3(dtc::kDecodeThreads), 0, s, p);
   DTC_CHECK_LAUNCH();
   return DTC_OK;

@@ -130,6 +130,23 @@ template <> __device__ __forceinline__ f32x2 mul_pair16<bf16_t>(uint32_t u, floa
 }
 template <> __device__ __forceinline__ f32x2 mul_pair16<float>(uint32_t, float) { return f32x2{0.f, 0.f}; }   // never instantiated for float maps
 
+// CONTRACT mode (dtc_roi_align_set_exact(0)) on 16-bit maps:  acc += float(x) * w  as ONE fused operation per element.
+// The reference is float-only (roi_align_forward_cuda.cu:199-208): on a 16-bit map there are no reference bits to match, north_star
+// asks for <= 1e-4 on the float32-accumulated result, and the exact path spends a third of its vector instructions on keeping the
+// multiply and the add of :75-77 apart (two roundings).  fp16: v_fma_mix_f32 converts, multiplies AND accumulates (one rounding);
+// bf16: two bit operations + v_pk_fma_f32.  |fused - unfused| <= a few float32 ulp of the largest partial sum (measured: bench line).
+template <typename T> __device__ __forceinline__ void fma_pair16(f32x2& acc, uint32_t u, float w);
+template <> __device__ __forceinline__ void fma_pair16<__half>(f32x2& acc, uint32_t u, float w) {
+  asm("v_fma_mix_f32 %0, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "+v"(acc.x), "+v"(acc.y) : "v"(u), "v"(w));
+}
+template <> __device__ __forceinline__ void fma_pair16<bf16_t>(f32x2& acc, uint32_t u, float w) {
+  const f32x2 v = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+  const f32x2 w2 = {w, w};
+  acc = __builtin_elementwise_fma(v, w2, acc);
+}
+template <> __device__ __forceinline__ void fma_pair16<float>(f32x2&, uint32_t, float) {}   // never instantiated for float maps
+
 // launchers of the cluster-stationary kernel (roi_align_tile.hip); in_dtype / out_dtype are DTC_* codes
 bool roi_align_tile_supported(const RoiAlignParams& p, int in_dtype, int out_dtype);
 int launch_roi_align_tile(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream);

@@ -166,7 +166,7 @@ struct TileGeom {            // one cluster, all uniform
 // KC * nq_pass <= kUnits.  Per pass:   commit(p) + store_slab(p-1) | barrier | issue(p+1) + pool(p) -> slab | barrier
 // i.e. the loads of pass p+1 are in flight (registers) while pass p is pooled, and the pooled [RoI][channel][bin] slab of
 // pass p leaves for global memory as contiguous 16-byte stores while pass p+1 is being committed.
-template <typename TIn, typename TOut, int NT>
+template <typename TIn, typename TOut, int NT, bool FUSED>
 __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_feat_level& L, const TIn* fbase, int c0, int nc,
                                             int bins, float* slab, typename TileLds<TIn>::T* win, const TileRoi* troi, const TileGeom& g,
                                             const TileItem& it, int rl, int bin, TileTrace& tt) {
@@ -322,7 +322,25 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
         // reference order: for iy { for ix { acc += w1*v1 + w2*v2 + w3*v3 + w4*v4 } }   (roi_align_cpu_loop.cpp:203-214)
 #pragma unroll
         for (int iy = 0; iy < 2; iy++) {
-          if constexpr (L16) {
+          if constexpr (L16 && FUSED) {
+            // contract mode (dtc_roi_align_set_exact(0)): every tap is one fused convert-multiply-accumulate per channel, 64
+            // vector instructions per channel quad instead of 64 + 32 packed adds (see fma_pair16)
+            u32x2 t[2][4];
+#pragma unroll
+            for (int ix = 0; ix < 2; ix++)
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                t[ix][k] = *reinterpret_cast<const u32x2*>(__builtin_assume_aligned(wq + it.a[iy][ix][k], 8));
+#pragma unroll
+            for (int ix = 0; ix < 2; ix++) {
+              const float w1 = it.yh[iy] * it.xh[ix], w2 = it.yh[iy] * it.xl[ix];
+              const float w3 = it.yl[iy] * it.xh[ix], w4 = it.yl[iy] * it.xl[ix];
+              fma_pair16<TIn>(a01, t[ix][0].x, w1); fma_pair16<TIn>(a23, t[ix][0].y, w1);
+              fma_pair16<TIn>(a01, t[ix][1].x, w2); fma_pair16<TIn>(a23, t[ix][1].y, w2);
+              fma_pair16<TIn>(a01, t[ix][2].x, w3); fma_pair16<TIn>(a23, t[ix][2].y, w3);
+              fma_pair16<TIn>(a01, t[ix][3].x, w4); fma_pair16<TIn>(a23, t[ix][3].y, w4);
+            }
+          } else if constexpr (L16) {
             u32x2 t[2][4];
 #pragma unroll
             for (int ix = 0; ix < 2; ix++)
@@ -385,7 +403,7 @@ __device__ __forceinline__ int tile_work_item(int b, int n, int reverse) {
   return start + ((reverse & 1) ? qx - 1 - j : j);
 }
 
-template <typename TIn, typename TOut, int NT>
+template <typename TIn, typename TOut, int NT, bool FUSED>
 __global__ __launch_bounds__(NT, (TileBounds<TIn, NT>::kWaves)) void roi_align_fwd_tile(RoiAlignParams p, int kgroup, int lds_bytes, int nq_cap, int merge_pct, int reverse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileRoi* troi = reinterpret_cast<TileRoi*>(smem);
@@ -581,7 +599,7 @@ __global__ __launch_bounds__(NT, (TileBounds<TIn, NT>::kWaves)) void roi_align_f
         it.a[iy][ix][0] = t0; it.a[iy][ix][1] = t1; it.a[iy][ix][2] = t2; it.a[iy][ix][3] = t3;
       }
     TT_MARK(2);
-    tile_passes<TIn, TOut, NT>(p, L, fbase, c0, nc, bins, slab, win, troi, g, it, rl, bin, tt);
+    tile_passes<TIn, TOut, NT, FUSED>(p, L, fbase, c0, nc, bins, slab, win, troi, g, it, rl, bin, tt);
   }
 #ifdef DTC_TILE_TRACE
   if (tid == 0 && blockIdx.x < 16384) {
@@ -625,7 +643,7 @@ static const TileConfig& tile_config() {   // A/B knobs (DTC_RA_TILE_CHBLOCK, DT
   return cfg;
 }
 
-template <typename TIn, typename TOut, int NT>
+template <typename TIn, typename TOut, int NT, bool FUSED>
 static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   const TileConfig& cfg = tile_config();
   const int bins = p.pooled_h * p.pooled_w;
@@ -637,7 +655,7 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_tile<TIn, TOut, NT>),
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(roi_align_fwd_tile<TIn, TOut, NT, FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   if (attr_rc != hipSuccess) return DTC_ELAUNCH;
@@ -651,14 +669,16 @@ static int launch_tile_nt(RoiAlignParams p, hipStream_t stream) {
   while (!cfg.ch_block && cb > 32 && (long long)ngrp * ceil_div(p.channels, cb) < 2048) cb >>= 1;
   p.ch_block = cb;
   const int nct = ceil_div(p.channels, p.ch_block);
-  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, (cfg.reverse ? 1 : 0) | (p.xcd_remap ? 0 : 2) | (cfg.cb_major ? 4 : 0));
+  hipLaunchKernelGGL((roi_align_fwd_tile<TIn, TOut, NT, FUSED>), dim3((unsigned)ngrp * nct), dim3(NT), lds_b, stream, p, K, lds_b, nq_cap, cfg.merge_pct, (cfg.reverse ? 1 : 0) | (p.xcd_remap ? 0 : 2) | (cfg.cb_major ? 4 : 0));
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }
 
 template <typename TIn, typename TOut>
 static int launch_tile_t(const RoiAlignParams& p, hipStream_t stream) {
-  return launch_tile_nt<TIn, TOut, 256>(p, stream);
+  // 16-bit maps in contract mode (dtc_roi_align_set_exact(0), read at launch time like the C4 kernel's fast mode): fused pooling
+  if constexpr (sizeof(TIn) == 2) { if (!roi_align_get_exact()) return launch_tile_nt<TIn, TOut, 256, true>(p, stream); }
+  return launch_tile_nt<TIn, TOut, 256, false>(p, stream);
 }
 
 bool roi_align_tile_supported(const RoiAlignParams& p, int in_dtype, int out_dtype) {

@@ -162,7 +162,9 @@ typedef struct dtc_rpn_level {
  * s = b * n_levels + l.  Outputs, per segment, in DESCENDING score order (ties: ascending (h,w,a) index):
  *   out_boxes float32 [B*L, k_stride, 4], out_scores float32 [B*L, k_stride], out_counts int32 [B*L]
  * i.e. exactly the `dets` the reference hands to NMS at :115.  k_stride >= max_l min(pre_nms_top_n_l, N_l) (0: that max).
- * (im_h, im_w) is the network input size (:100), min_size_scaled = rpn_min_size * scaling_factor (:154). */
+ * (im_h, im_w) is the network input size (:100), min_size_scaled = rpn_min_size * scaling_factor (:154).
+ * The workspace must be EXCLUSIVE to one in-flight call: it holds the histograms, tickets and block counts the kernels of the call
+ * hand to each other (calls on different streams need different workspaces; calls on one stream may share one). */
 size_t dtc_rpn_topk_decode_workspace_bytes(const dtc_rpn_level* levels, int n_levels, int batch, int k_stride);
 int dtc_rpn_topk_decode(const dtc_rpn_level* levels, int n_levels, int batch, float im_h, float im_w,
                         float min_size_scaled, void* workspace, size_t workspace_bytes, float* out_boxes,

@@ -166,6 +166,35 @@ def test_negative_count_leaves_segment_untouched(hip, oracle):
         assert cnt[1] == -7 and (keep[1] == -7).all()
 
 
+def test_negative_count_in_two_phase_path(hip, oracle):
+    """The same protocol through the keep[:max_keep] path of LONG segments (N = 6000, max_keep = 1000: two phases, the second one
+    runs on a per-segment count array the first one writes).  A caller-supplied negative count must survive both phases: the
+    workspace is pre-filled with a POSITIVE garbage pattern, so a phase-1 early-out that forgets to forward the -1 shows up as an
+    overwritten keep list (round-5 advisor finding)."""
+    N, cap = 6000, 1000
+    d0, d1 = _c4_like_sorted_dets(11, N, 84), _c4_like_sorted_dets(12, N, 10)
+    boxes = np.zeros((4, N, 4), np.float32)
+    boxes[0] = d0[:, :4]; boxes[1] = d1[:, :4]; boxes[2] = d1[:, :4]; boxes[3] = d0[:, :4]
+    L = hip.lib()
+    dev = torch.device("cuda", 0)
+    nbytes = L.dtc_nms_sorted_workspace_bytes(4, N)
+    ws = torch.full((nbytes // 4,), 5000, dtype=torch.int32, device=dev)          # stale positive "counts" everywhere
+    keep = torch.full((4, cap), -7, dtype=torch.int32, device=dev)
+    cnt = torch.full((4,), -7, dtype=torch.int32, device=dev)
+    counts = torch.tensor([N, -1, N, -1], dtype=torch.int32, device=dev)
+    bt = torch.from_numpy(boxes).cuda()
+    hip.check(L.dtc_nms_sorted(bt.data_ptr(), counts.data_ptr(), 4, N, 0.7, cap, ws.data_ptr(), nbytes, keep.data_ptr(), cap,
+                               cnt.data_ptr(), hip.stream_ptr(dev)), "nms_sorted")
+    torch.cuda.synchronize()
+    keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+    r0, r2 = np.sort(oracle.nms(d0, 0.7, max_keep=cap)), np.sort(oracle.nms(d1, 0.7, max_keep=cap))
+    assert int(r2[-1]) >= 2048                                                     # segment 2 really needs the second phase
+    assert cnt[0] == len(r0) and np.array_equal(keep[0, :cnt[0]], r0)
+    assert cnt[2] == len(r2) and np.array_equal(keep[2, :cnt[2]], r2)
+    for s_ in (1, 3):
+        assert cnt[s_] == -7 and (keep[s_] == -7).all(), s_
+
+
 def test_idempotence_full_size(hip):
     # size-independent property at BASELINE cfg2's full size (6000 pre-NMS boxes): NMS of the survivors keeps them all
     d = _dets(4242, 6000)

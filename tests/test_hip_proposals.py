@@ -161,3 +161,102 @@ def test_logit_input_equals_materialised_sigmoid(hip, oracle):
             rb, rsc, rpb, rps = oracle.generate_proposals(prob[b], d[b], oa, stride, 800, 1344, pre, 1000, 0.7, return_pre_nms=True)
             assert n == rps.shape[0] and np.array_equal(fps[b, :n], rps) and np.array_equal(fpb[b, :n], rpb)
             assert m == rsc.shape[0] and np.array_equal(fs[b, 0, :m], rsc) and np.array_equal(fb[b, 0, :m], rb)
+
+
+# ---- long segments: the LSD radix sort of rpn_sort (more than 2048 keys to order), with TIED scores ---------------------------
+# (round-5 review: every test that reached block_radix_sort_u64 used tie-free scores, for which the index digits never decide an
+# ordering.)  generate_proposals.py:77-93 with pre_nms_top_n = 6000: pre-NMS boxes, scores and counts bit-equal to the oracle.
+def _c4_tie_maps(rs, A, H, W):
+    c, d = synth.make_rpn_outputs(rs, A, H, W, tie_free=False)
+    sparse = np.zeros_like(c)                                   # fewer than 6000 elements above the floor value: the rest of the
+    pick = rs.permutation(c.size)[:3500]                        # top-6000 are ties AT the floor, taken in index order
+    sparse.reshape(-1)[pick] = c.reshape(-1)[pick]
+    two = np.where(c > np.median(c), np.float32(0.75), np.float32(0.25)).astype(np.float32)
+    return d, [("q16", (np.round(c * 16) / 16).astype(np.float32)),
+               ("q4096", (np.round(c * 4096) / 4096).astype(np.float32)),
+               ("const", np.full_like(c, 0.25)),
+               ("saturated", np.ones_like(c)),
+               ("sparse", sparse),
+               ("two_values", two)]
+
+
+def _check_pre_nms(hip, oracle, sc, d, anchors, stride, pre, im_h=800, im_w=1333):
+    _, _, _, pb, ps, pc = hip.generate_proposals([torch.from_numpy(sc).cuda()], [torch.from_numpy(d).cuda()], [anchors],
+                                                 [stride], im_h, im_w, [pre], 1000, 0.7)
+    _, _, rpb, rps = oracle.generate_proposals(sc[0], d[0], anchors, stride, im_h, im_w, pre, 1000, 0.7, return_pre_nms=True)
+    n = int(pc.cpu().numpy()[0])
+    assert n == rps.shape[0]
+    assert np.array_equal(ps.cpu().numpy()[0, :n], rps)
+    assert np.array_equal(pb.cpu().numpy()[0, :n], rpb)
+    return n
+
+
+@pytest.mark.parametrize("pre", [6000, 3000, 8192, 10000])
+def test_c4_size_ties_reach_radix_sort(hip, oracle, pre):
+    # A = 15 on 50 x 84; pre = 6000 / 3000 / 8192 -> the radix branch (sort_cap 8192 / 4096 / 8192), 10000 -> the 16-keys-per-thread
+    # bitonic branch; "const" / "saturated" / "two_values" also go through the in-workgroup radix select that precedes the sort
+    from detectorch_amd.utils.generate_anchors import generate_anchors
+    anchors = generate_anchors(stride=16.0)
+    d, maps = _c4_tie_maps(synth.rng(2, 4100 + pre), 15, 50, 84)
+    for name, sc in maps:
+        n = _check_pre_nms(hip, oracle, sc, d, anchors, 16.0, pre)
+        assert n > 2048, name
+
+
+@pytest.mark.parametrize("A,H,W", [(16, 64, 64), (1, 257, 256), (16, 64, 65)])
+def test_radix_sort_index_digit_boundary(hip, oracle, A, H, W):
+    # idx_bits = bits of N - 1 decides which index digits the sort visits: N = 65 536 (16 bits: two index digits), 65 792 and
+    # 66 560 (17 bits: three).  Quantised scores -> thousands of exact ties ordered by the index digits alone.
+    from detectorch_amd.utils.generate_anchors import generate_anchors
+    sizes = (32.0,) if A == 1 else (32, 64, 128, 256)
+    ratios = (1.0,) if A == 1 else (0.5, 1, 2, 4)
+    anchors = generate_anchors(stride=16.0, sizes=sizes, aspect_ratios=ratios)
+    assert anchors.shape[0] == A
+    rs = synth.rng(2, 5200 + W)
+    c, d = synth.make_rpn_outputs(rs, A, H, W, tie_free=False)
+    for q in (8, 512):
+        sc = (np.round(c * q) / q).astype(np.float32)
+        assert _check_pre_nms(hip, oracle, sc, d, anchors, 16.0, 6000, im_h=16 * H, im_w=16 * W) > 2048
+    assert _check_pre_nms(hip, oracle, np.full_like(c, 0.5), d, anchors, 16.0, 6000, im_h=16 * H, im_w=16 * W) > 2048
+
+
+def test_radix_sort_24bit_index(hip, oracle):
+    # N = 2^24 + 4096 anchors (25 index bits: all four index digits in use); two score values
+    from detectorch_amd.utils.generate_anchors import generate_anchors
+    A, H, W = 1, 4097, 4096
+    anchors = generate_anchors(stride=4.0, sizes=(32.0,), aspect_ratios=(1.0,))
+    rs = synth.rng(2, 6300)
+    sc = np.full((1, A, H, W), 0.25, np.float32)
+    hot = rs.permutation(A * H * W)[:2500]
+    sc.reshape(-1)[hot] = 0.75
+    d = (rs.standard_normal((1, 4 * A, H, W)).astype(np.float32) * np.float32(0.2))
+    assert _check_pre_nms(hip, oracle, sc, d, anchors, 4.0, 6000, im_h=4 * H, im_w=4 * W) > 2048
+
+
+def test_c4_path_graph_replay_with_ties(hip, oracle):
+    # the same tie cases through C4RegionPath's captured hipGraph, replayed twice with different score maps in the bound tensors
+    from detectorch_amd.pipeline import C4RegionPath, synthetic_c4_batch
+    dev = torch.device("cuda", 0)
+    B = 2
+    path = C4RegionPath(B, dev, channels=8)
+    inputs = list(synthetic_c4_batch(B, dev, seed=2600, channels=8))
+    path.bind(*inputs)
+    anchors = oracle.generate_anchors(16.0)
+    for q in (16, 4096, 0):
+        c = inputs[0]
+        c.copy_(torch.round(c * q) / q if q else torch.full_like(c, 0.25))
+        path.step(use_graph=True)
+        torch.cuda.synchronize()
+        sc, d = inputs[0].cpu().numpy(), inputs[1].cpu().numpy()
+        pb, ps, pc = path.pre_boxes.cpu().numpy(), path.pre_scores.cpu().numpy(), path.pre_counts.cpu().numpy()
+        kc = path.keep_cnt.cpu().numpy()
+        for b in range(B):
+            rb, rsc, rpb, rps = oracle.generate_proposals(sc[b], d[b], anchors, 16.0, path.im_h, path.im_w, 6000, 1000, 0.7,
+                                                          return_pre_nms=True)
+            n = int(pc[b])
+            assert n == rps.shape[0] and n > 2048
+            assert np.array_equal(ps[b, :n], rps) and np.array_equal(pb[b, :n], rpb)
+            m = int(kc[b])
+            assert m == rb.shape[0]
+            assert np.array_equal(path.prop_boxes[b, :m].cpu().numpy(), rb)
+            assert np.array_equal(path.prop_scores[b, :m].cpu().numpy(), rsc)
