@@ -237,6 +237,112 @@ def recorded_traffic(wl, batch, channels_last, fp16, k_ms):
     return traffic, traffic_src, l1_fills
 
 
+def launch_ms(fn, iters, warm=3):
+    """Mean duration of `fn` (one kernel launch on the current stream) over `iters` launches, HIP events on that stream."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def c4_modes(paths, iters, alg):
+    """cfg2's RoIAlign launch beyond the exact float32 mode the steps ran in: the contract-legal FAST mode
+    (dtc_roi_align_set_exact(0): merged taps, <= 1e-5 from exact, north_star allows 1e-4) and the 16-bit OUTPUT form (bf16 pooled
+    features straight into the res5 head) with its own algorithmic bytes, exact and fast."""
+    from detectorch_amd import hip
+    p0 = paths[0]
+    L = hip.lib()
+    box = lambda k: (lambda: paths[k % len(paths)]._roi_align_box())
+    k = [0]
+
+    def rot():
+        paths[k[0] % len(paths)]._roi_align_box()
+        k[0] += 1
+    p0._roi_align_box()
+    torch.cuda.synchronize()
+    exact_feats = p0.box_feats.clone()
+    out16 = torch.empty(p0.box_feats.shape, dtype=torch.bfloat16, device=p0.dev)
+
+    def to16():
+        hip.check(L.dtc_roi_align_forward_packed_ws(p0.feat_lv, 1, p0.C, p0.feat_code, p0.roi_desc.data_ptr(), p0.B * p0.top_n,
+                                                    p0.pooled, p0.pooled, p0.sr, out16.data_ptr(), hip.DTC_BF16,
+                                                    p0.ra_ws.data_ptr(), p0.ra_ws.numel(), hip.stream_ptr(p0.dev)), "roi_align(c4, bf16 out)")
+    alg16 = alg - exact_feats.numel() * exact_feats.element_size() + out16.numel() * 2
+    frac = lambda bytes_, ms: round(bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    res = {}
+    e16 = launch_ms(to16, iters)
+    torch.cuda.synchronize()
+    ok16 = bool(torch.equal(out16, exact_feats.to(torch.bfloat16)))
+    if not ok16:
+        raise SystemExit("cfg2: bf16 output != float32 output rounded once")
+    hip.roi_align_set_exact(False)
+    try:
+        f_ms = launch_ms(rot, iters)
+        p0._roi_align_box()
+        torch.cuda.synchronize()
+        dev_fast = float((p0.box_feats.float() - exact_feats.float()).abs().max())
+        f16 = launch_ms(to16, iters)
+        torch.cuda.synchronize()
+        dev16 = float((out16.float() - exact_feats).abs().max())
+    finally:
+        hip.roi_align_set_exact(True)
+        for pth in paths:                 # leave exact results behind
+            pth._roi_align_box()
+        torch.cuda.synchronize()
+    res["fast_mode"] = {"launch_ms": round(f_ms, 4), "frac": frac(alg, f_ms), "max_abs_diff_vs_exact": dev_fast,
+                        "what": "dtc_roi_align_set_exact(0): (gh+1)x(gw+1) merged taps with separable weight sums instead of gh x gw x 4 "
+                                "(contract: <= 1e-4 on pooled features); the timed steps and the parity check ran in exact mode"}
+    res["bf16_output"] = {"algorithmic_bytes_per_launch": int(alg16),
+                          "exact": {"launch_ms": round(e16, 4), "frac": frac(alg16, e16), "equals_float32_output_rounded_once": ok16},
+                          "fast_mode": {"launch_ms": round(f16, 4), "frac": frac(alg16, f16), "max_abs_diff_vs_exact_float32": dev16},
+                          "what": "the same launch writing bf16 pooled features (v_cvt_pk_bf16_f32 in the store path; SURVEY 8f-2: the res5 "
+                                  "head's GEMM input type) -- half the output bytes of a launch that is 95 % writes"}
+    return res
+
+
+def cfg5_modes(paths, iters, alg, dev):
+    """cfg5 runs in CONTRACT mode (dtc_roi_align_set_exact(0)); this times the same box-head launch in EXACT mode and measures how far
+    the two are apart: on the fp16 output (ulps) and on a float32 output of the same 16 000 descriptors (the quantity north_star's
+    1e-4 is about).  Outside the tolerance aborts the run.  Leaves contract-mode results behind."""
+    from detectorch_amd import hip
+    extra = {}
+    p0 = paths[0]
+    rot_i = [0]
+
+    def rot():
+        paths[rot_i[0] % len(paths)]._roi_align_box()
+        rot_i[0] += 1
+    o32 = torch.empty(p0.box_feats.shape, dtype=torch.float32, device=dev)
+    to32 = lambda: hip.check(hip.lib().dtc_roi_align_forward_packed(p0.feat_lv, 4, p0.C, p0.feat_code, p0.roi_desc.data_ptr(), p0.B * p0.top_n,
+                                                                  p0.box_p, p0.box_p, p0.sr, o32.data_ptr(), hip.DTC_F32, hip.stream_ptr(dev)), "roi_align f32 out")
+    p0._roi_align_box(); to32()
+    torch.cuda.synchronize(dev)
+    c16, c32 = p0.box_feats.clone(), o32.clone()
+    hip.roi_align_set_exact(True)
+    try:
+        x_ms = launch_ms(rot, iters)
+        p0._roi_align_box(); to32()
+        torch.cuda.synchronize(dev)
+        ulp = (c16.view(torch.int16).int() - p0.box_feats.view(torch.int16).int()).abs()
+        extra["exact_mode"] = {"launch_ms": round(x_ms, 4), "frac": round(alg / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "what": "dtc_roi_align_set_exact(1): the reference's separate multiply and add on the up-cast maps, bit-equal to the CPU checker (tests)"}
+        extra["contract_vs_exact"] = {"max_abs_diff_float32_output": float((c32 - o32).abs().max()), "tolerance": 1e-4,
+                                      "fp16_output_max_ulp": int(ulp.max()), "fp16_output_fraction_differing": float((ulp != 0).float().mean())}
+        if extra["contract_vs_exact"]["max_abs_diff_float32_output"] > 1e-4 or extra["contract_vs_exact"]["fp16_output_max_ulp"] > 1:
+            raise SystemExit("cfg5 contract mode outside its tolerance")
+    finally:
+        hip.roi_align_set_exact(False)
+        for pth in paths:
+            pth._roi_align_box()
+        torch.cuda.synchronize(dev)
+    return extra
+
+
 def side_leg(wl, channels_last, a, dev, steps, cpu_images):
     """A SHORT leg of another BASELINE configuration in the same process, after the contract line's timed region (VERDICT r04 item 2:
     cfg5 / cfg2 figures were builder-run only).  Same construction as the headline: two bound input sets, hipGraph replay, two steps in
@@ -247,6 +353,11 @@ def side_leg(wl, channels_last, a, dev, steps, cpu_images):
     fp16 = wl == "cfg5"
     fdt = torch.float16 if fp16 else torch.float32
     top_n = 2000 if wl == "cfg5" else 1000
+    # cfg5 (16-bit maps): the steps run in CONTRACT mode -- dtc_roi_align_set_exact(0), fused convert-multiply-accumulate pooling.  The
+    # reference is float-only (roi_align_forward_cuda.cu:199-208): on fp16 maps there are no reference bits, the contract is <= 1e-4 on
+    # the float32-accumulated result.  The exact-mode launch (the reference's unfused order on the up-cast maps) is timed beside it.
+    contract = wl == "cfg5"
+    hip.roi_align_set_exact(not contract)          # read at launch / capture time
     paths, inputs = [], []
     for s in range(2):
         seed = {"cfg3": 3000, "cfg5": 5000, "cfg2": 2000}[wl] + 500 * s
@@ -290,11 +401,18 @@ def side_leg(wl, channels_last, a, dev, steps, cpu_images):
     k_ms = float(np.mean(k_all))
     alg = paths[0].box_roialign_bytes()
     traffic, traffic_src, _ = recorded_traffic(wl, a.batch, channels_last, fp16, k_ms)
+    extra = {}
+    if contract:
+        extra.update(cfg5_modes(paths, iters, alg, dev))
+    if wl == "cfg2":
+        extra.update(c4_modes(paths, iters, alg))
     paths[0].step(use_graph=not a.eager)
     torch.cuda.synchronize(dev)
     cb = cpu_baseline(wl, inputs[0], paths[0], cpu_images, a.c4_pooled, image_parallel=False)
+    hip.roi_align_set_exact(True)
     out = {"workload_id": wl, "feature_layout": "NHWC" if channels_last else "NCHW", "dtype": "f16" if fp16 else "f32",
            "rois_per_image": top_n, "images_per_gpu_per_step": a.batch, "steps": steps,
+           "roi_align_mode": "contract (dtc_roi_align_set_exact(0): fused fp32 accumulate on the 16-bit maps)" if contract else "exact",
            "value": round(a.batch / t2, 2), "unit": "images/sec", "ms_per_step": round(t2 * 1e3, 4),
            "one_stream_ms_per_step": round(t1 * 1e3, 4),
            "roofline": {"bound": "hbm", "kernel": "roi_align (box head)", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
@@ -302,6 +420,7 @@ def side_leg(wl, channels_last, a, dev, steps, cpu_images):
                         "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(k_ms, 4),
                         "launch_ms_min_median_max": [round(float(np.min(k_all)), 4), round(float(np.median(k_all)), 4), round(float(np.max(k_all)), 4)]},
            "parity_checked": cb["parity_checked"], "cpu_baseline_images_per_sec": cb["value"]}
+    out["roofline"].update(extra)
     del paths, inputs
     torch.cuda.empty_cache()
     return out
@@ -361,6 +480,8 @@ def main():
     fdt = torch.float16 if fp16 else torch.float32
     top_n = 2000 if wl == "cfg5" else 1000
     NSETS = max(2, a.inflight)
+    contract = wl == "cfg5" and fp16       # 16-bit maps: contract mode (see side_leg); read at launch / graph-capture time
+    hip.roi_align_set_exact(not contract)
     paths, inputs = [], []
     for s in range(NSETS):
         seed = {"cfg3": 3000, "cfg5": 5000, "cfg2": 2000}[wl] + 500 * s + rank
@@ -463,31 +584,7 @@ def main():
     k_ms = float(np.mean(k_all))
     alg_bytes = paths[0].box_roialign_bytes()
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    fast_mode = None
-    if wl == "cfg2":                          # the same launch in the kernel's FAST mode (dtc_roi_align_set_exact(0): merged taps, not bit-identical)
-        exact_feats = paths[0].box_feats.clone()
-        hip.roi_align_set_exact(False)
-        try:
-            for _ in range(3):
-                paths[0]._roi_align_box()
-            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            f0.record()
-            for it_ in range(iters):
-                paths[it_ % NSETS]._roi_align_box()
-            f1.record()
-            torch.cuda.synchronize(dev)
-            f_ms = f0.elapsed_time(f1) / iters
-            paths[0]._roi_align_box()
-            torch.cuda.synchronize(dev)
-            fast_mode = {"launch_ms": round(f_ms, 4), "frac": round(alg_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "max_abs_diff_vs_exact": float((paths[0].box_feats.float() - exact_feats.float()).abs().max()),
-                         "what": "dtc_roi_align_set_exact(0): (gh+1)x(gw+1) merged taps with separable weight sums instead of gh x gw x 4; "
-                                 "the timed steps and the parity check above ran in exact mode"}
-        finally:
-            hip.roi_align_set_exact(True)
-            for pth in paths:                 # leave exact results behind
-                pth._roi_align_box()
-            torch.cuda.synchronize(dev)
+    c4_extra = c4_modes(paths, iters, alg_bytes) if wl == "cfg2" else cfg5_modes(paths, iters, alg_bytes, dev) if contract else {}
     harder = None
     if wl != "cfg2":                          # the same launch on the harder RoI population (a trained RPN looks like it)
         h_ms = harder_set_launch(paths[0], inputs[0][2], top_n, dev, max(5, iters // 2))
@@ -547,6 +644,11 @@ def main():
             desc = ("BASELINE configs[%d]: Mask R-CNN R-50-FPN, 1x3x800x1333 (padded 800x1344), 5-level RPN (268569 anchors) -> %d rois, "
                     "4-level RoIAlign 7x7 sr2 C256%s, 81-class postprocess, RoIAlign 14x14 mask branch, 28x28 mask paste"
                     % (4 if wl == "cfg5" else 2, top_n, " fp16 features" if fp16 else ""))
+            if wl == "cfg3" and world * a.batch == 64 and world == 8:
+                # 8 GPUs x 8 images = BASELINE configs[3] (Mask R-CNN R-101-FPN, batch 64 over 8 MI355X): the hot-path shapes are those of
+                # configs[2] -- R-101 only deepens the backbone, which is not in the path
+                desc = desc.replace("BASELINE configs[2]: Mask R-CNN R-50-FPN", "BASELINE configs[3]: Mask R-CNN R-101-FPN, batch 64 sharded over 8 GPUs "
+                                    "(hot-path shapes == configs[2]; the deeper backbone is not in the path)")
             kern = "roi_align (box head, 4 levels, %d rois)" % (a.batch * top_n)
             not_in = "ResNet-50/FPN convs and box/mask-head GEMMs (MIOpen/hipBLASLt), outputs synthetic"
         out = {
@@ -560,6 +662,7 @@ def main():
                        "detection_rows_per_image": None if wl == "cfg2" else a.max_out,
                        "input_sets_rotated": NSETS,
                        "feature_layout": "NHWC" if a.channels_last else "NCHW",
+                       "roi_align_mode": "contract (dtc_roi_align_set_exact(0): fused fp32 accumulate on the 16-bit maps)" if contract else "exact",
                        "launch": ("eager" if a.eager else "hipGraph") + (", %d sub-batches on %d streams" % (a.split, a.split) if isinstance(p0, OverlappedRegionPath) else "") +
                                  (", %d steps in flight on %d HIP streams (StepPipeline)" % (a.inflight, a.inflight) if a.inflight > 1 else ""),
                        "steps_in_flight": a.inflight,
@@ -593,7 +696,9 @@ def main():
                                                                       "images_per_sec": round(a.batch * n_sus * world / dt_sus, 2)}},
         }
         out["roofline"]["harder_set"] = harder
-        out["roofline"]["fast_mode"] = fast_mode
+        # first-class beside `frac`: the same launch on the RoI population a trained RPN produces
+        out["roofline"]["frac_harder"] = None if harder is None else harder["frac"]
+        out["roofline"].update(c4_extra)
         if not a.no_cpu_baseline and not isinstance(p0, OverlappedRegionPath):
             p0.step(use_graph=not a.eager)          # the configuration that was timed, on input set 0
             torch.cuda.synchronize(dev)
@@ -606,10 +711,13 @@ def main():
             del pipe
             paths.clear(); inputs.clear()
             torch.cuda.empty_cache()
-            out["other_workloads"] = {
-                "cfg5_nhwc": side_leg("cfg5", True, a, dev, a.side_steps, 2),
-                "cfg5_nchw": side_leg("cfg5", False, a, dev, a.side_steps, 2),
-                "cfg2": side_leg("cfg2", False, a, dev, a.side_steps, 2)}
+            out["other_workloads"] = {}
+            for name, (wl_s, cl_s) in (("cfg5_nhwc", ("cfg5", True)), ("cfg5_nchw", ("cfg5", False)), ("cfg2", ("cfg2", False))):
+                try:      # a failing side leg (OOM, a parity abort) must not discard the headline line measured above
+                    out["other_workloads"][name] = side_leg(wl_s, cl_s, a, dev, a.side_steps, 2)
+                except BaseException as e:   # SystemExit of a parity abort included: recorded, not swallowed silently
+                    out["other_workloads"][name] = {"error": repr(e)}
+                    hip.roi_align_set_exact(True)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -40,7 +40,7 @@ template <> __device__ __forceinline__ f32x2 n16_tap_pair<float>(const uint32_t*
 }
 
 // the 16 taps of one bin (8 channels each) and the pooled 8 channels -> slab.  ADDR: callable (y_off, x_off) -> uint4
-template <typename TIn, typename TOut, typename LD>
+template <typename TIn, typename TOut, bool FUSED, typename LD>
 __device__ __forceinline__ void n16_pool_bin(const N16Tab& y0e, const N16Tab& y1e, const N16Tab& x0e, const N16Tab& x1e, LD ld,
                                              TOut* so, int bins) {
   uint4 t[16];        // all 16 taps in flight before the first one is consumed
@@ -62,6 +62,15 @@ __device__ __forceinline__ void n16_pool_bin(const N16Tab& y0e, const N16Tab& y1
     const uint32_t* u2 = reinterpret_cast<const uint32_t*>(&t[sidx * 4 + 1]);
     const uint32_t* u3 = reinterpret_cast<const uint32_t*>(&t[sidx * 4 + 2]);
     const uint32_t* u4 = reinterpret_cast<const uint32_t*>(&t[sidx * 4 + 3]);
+    if constexpr (FUSED && sizeof(TIn) == 2) {
+      // contract mode on 16-bit maps (dtc_roi_align_set_exact(0)): one fused convert-multiply-accumulate per element (fma_pair16)
+#pragma unroll
+      for (int k = 0; k < PP; k++) {
+        fma_pair16<TIn>(a[k], u1[k], w1); fma_pair16<TIn>(a[k], u2[k], w2);
+        fma_pair16<TIn>(a[k], u3[k], w3); fma_pair16<TIn>(a[k], u4[k], w4);
+      }
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < PP; k++) {          // pair k: channels 2k and 2k + 1 of the lane
       f32x2 s = n16_tap_pair<TIn>(u1, k, w1) + n16_tap_pair<TIn>(u2, k, w2);
@@ -78,7 +87,7 @@ __device__ __forceinline__ void n16_pool_bin(const N16Tab& y0e, const N16Tab& y1
 }
 
 // CB: channels per workgroup (64, or 32 when a 64-channel slab of one RoI exceeds the budget: 14 x 14 bins with float32 output)
-template <typename TIn, typename TOut, int CB>
+template <typename TIn, typename TOut, int CB, bool FUSED>
 // (98 VGPRs: four workgroups per CU; bounding it to five -- 96 VGPRs -- measured no difference and spilled the bf16 variants)
 __global__ __launch_bounds__(kN16Threads) void roi_align_fwd_nhwc16(RoiAlignParams p, const char* base0, int G) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -150,10 +159,10 @@ __global__ __launch_bounds__(kN16Threads) void roi_align_fwd_nhwc16(RoiAlignPara
         for (int k = 0; k < CPL; k++) n16_put<TOut>(so + k * bins, 0.f);
       } else if constexpr (FAR) {
         const char* lbase = info.ptr + ESZ * c0 + lane_off;
-        n16_pool_bin<TIn, TOut>(y0e, y1e, x0e, x1e, [&](uint32_t yo, uint32_t xo) { return *reinterpret_cast<const uint4*>(lbase + (yo + xo)); }, so, bins);
+        n16_pool_bin<TIn, TOut, FUSED>(y0e, y1e, x0e, x1e, [&](uint32_t yo, uint32_t xo) { return *reinterpret_cast<const uint4*>(lbase + (yo + xo)); }, so, bins);
       } else {
         const uint32_t lo = info.rebase + lane_off;
-        n16_pool_bin<TIn, TOut>(y0e, y1e, x0e, x1e, [&](uint32_t yo, uint32_t xo) { return *reinterpret_cast<const uint4*>(sbase + (yo + lo + xo)); }, so, bins);
+        n16_pool_bin<TIn, TOut, FUSED>(y0e, y1e, x0e, x1e, [&](uint32_t yo, uint32_t xo) { return *reinterpret_cast<const uint4*>(sbase + (yo + lo + xo)); }, so, bins);
       }
       pw += step_w; if (pw >= p.pooled_w) { pw -= p.pooled_w; ph++; }
       ph += step_h; if (ph >= p.pooled_h) { ph -= p.pooled_h; rl++; }
@@ -210,7 +219,7 @@ bool roi_align_nhwc16_supported(const RoiAlignParams& p, int in_dtype, int out_d
   return true;
 }
 
-template <typename TIn, typename TOut, int CB>
+template <typename TIn, typename TOut, int CB, bool FUSED>
 static int launch_n16_t(const RoiAlignParams& p, hipStream_t stream) {
   const int bins = p.pooled_h * p.pooled_w, ne = 2 * (p.pooled_h + p.pooled_w);
   int G = (int)(kN16SlabBytes / ((size_t)CB * bins * sizeof(TOut)));
@@ -220,14 +229,17 @@ static int launch_n16_t(const RoiAlignParams& p, hipStream_t stream) {
   const size_t smem = kN16MaxG * sizeof(N16Roi) + (size_t)G * ne * sizeof(N16Tab) + (size_t)G * CB * bins * sizeof(TOut);
   const int nct = p.channels / CB;
   const int ngrp = (p.n_rois + G - 1) / G;
-  hipLaunchKernelGGL((roi_align_fwd_nhwc16<TIn, TOut, CB>), dim3((unsigned)ngrp * nct), dim3(kN16Threads), smem, stream, p, base0, G);
+  hipLaunchKernelGGL((roi_align_fwd_nhwc16<TIn, TOut, CB, FUSED>), dim3((unsigned)ngrp * nct), dim3(kN16Threads), smem, stream, p, base0, G);
   DTC_CHECK_LAUNCH();
   return DTC_OK;
 }
 
 template <typename TIn, typename TOut>
 static int launch_n16_cb(const RoiAlignParams& p, int cb, hipStream_t stream) {
-  return cb == 64 ? launch_n16_t<TIn, TOut, 64>(p, stream) : launch_n16_t<TIn, TOut, 32>(p, stream);
+  if constexpr (sizeof(TIn) == 2) {       // contract mode, read at launch time (roi_align_common.h: fma_pair16)
+    if (!roi_align_get_exact()) return cb == 64 ? launch_n16_t<TIn, TOut, 64, true>(p, stream) : launch_n16_t<TIn, TOut, 32, true>(p, stream);
+  }
+  return cb == 64 ? launch_n16_t<TIn, TOut, 64, false>(p, stream) : launch_n16_t<TIn, TOut, 32, false>(p, stream);
 }
 
 int launch_roi_align_nhwc16(const RoiAlignParams& p, int in_dtype, int out_dtype, hipStream_t stream) {
