@@ -11,6 +11,7 @@
 //                    `>=` filter (ties kept, like the reference), class-major / roi-ascending output (:165).
 #include "block_sort.h"
 #include "dtc_common.h"
+#include "fpn_map.h"
 #include "radix_select.h"
 
 namespace dtc {
@@ -88,28 +89,31 @@ __global__ __launch_bounds__(kDetThreads) void det_softmax_stats_kernel(const fl
 __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-  __shared__ int wave_tot[kDetThreads / 64];
   __shared__ int running;
   const int j = blockIdx.x + 1, b = blockIdx.y;
   const int seg = b * (p.n_cls - 1) + (j - 1);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nr = p.n_rois ? min(p.n_rois[b], p.R) : p.R;
   const float* sc = p.cls_score + (size_t)b * p.R * p.n_cls + j;
-  int32_t* qroi = p.q_roi + (size_t)seg * p.R;
   float* qs = p.q_scores + (size_t)seg * p.R;
   [[maybe_unused]] const int ptb = blockIdx.y * gridDim.x + blockIdx.x;
   DTC_PT(0, ptb, 0);
   if (tid == 0) running = 0;
   __syncthreads();
-  // ordered compaction of {r : scores[r, j] > thresh}  (np.where, result_utils.py:127).  The scores of FOUR chunks of 256 rois are
-  // requested before the first is consumed (one global round trip per 1024 rois instead of one per 256: 5.7 -> ~3 us at 1000 rois)
-  for (int R0 = 0; R0 < nr; R0 += 4 * kDetThreads) {
+  // compaction of {r : scores[r, j] > thresh}  (np.where, result_utils.py:127).  Round 6: UNORDERED -- a wave claims its slots with
+  // one LDS atomic, no workgroup barrier per chunk.  Nothing downstream depends on the slot order: the sort key carries the ROI INDEX r
+  // ((score desc, r asc) is the order (score desc, candidate index asc) was, the candidate index being monotone in r), and the
+  // per-candidate scratch (q_boxes / q_scores) is indexed by r.  The scores of FOUR chunks of 256 rois are requested before the first
+  // is consumed, and before the image's roi count is known (the array is [B, R, n_cls]: every address is valid; rows past the count
+  // are masked afterwards) -- one global round trip in front of the first compare instead of two dependent ones.
+  int R0 = 0;
+  do {
     float sv[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int r = R0 + u * kDetThreads + tid;
       sv[u] = 0.f;
-      if (r < nr) {
+      if (r < p.R) {
         sv[u] = sc[(size_t)r * p.n_cls];
         if (p.sm_stats) {      // logits in: softmax column formed here (detector.py:281)
           const double* st = p.sm_stats + ((size_t)b * p.R + r) * 2;
@@ -119,26 +123,22 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int r0 = R0 + u * kDetThreads;
-      if (r0 >= nr) break;                                     // uniform
-      const int r = r0 + tid;
+      const int r = R0 + u * kDetThreads + tid;
       const float s = sv[u];
       const bool ok = r < nr && s > p.score_thresh;
       const uint64_t m = __ballot(ok);
-      if (lane == 0) wave_tot[wv] = __builtin_popcountll(m);
-      __syncthreads();
-      int base = running;
-      for (int q = 0; q < wv; q++) base += wave_tot[q];
+      if (m == 0ull) continue;                                 // uniform per wave
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&running, __builtin_popcountll(m));
+      base = __builtin_amdgcn_readfirstlane(base);
       if (ok) {
-        const int q = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-        qroi[q] = r; qs[q] = s;
-        keys[q] = make_desc_key(s, (uint32_t)q);
+        qs[r] = s;
+        keys[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_desc_key(s, (uint32_t)r);
       }
-      __syncthreads();
-      if (tid == 0) { int t = 0; for (int q = 0; q < kDetThreads / 64; q++) t += wave_tot[q]; running += t; }
-      __syncthreads();
     }
-  }
+    R0 += 4 * kDetThreads;
+  } while (R0 < nr);
+  __syncthreads();
   const int n = running;
   if (tid == 0) {
     p.cand_count[seg] = n;
@@ -150,35 +150,31 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
   for (int i = n + tid; i < np2; i += kDetThreads) keys[i] = kPadKey;
   block_bitonic_sort<kDetThreads>(keys, np2);
   DTC_PT(0, ptb, 2);
-  // decode candidate q (once), then emit both the candidate-order and the score-order copies
+  // the box of rank k (decoded once): to q_boxes[r] for det_finalize, and in SCORE order for the NMS below -- in LDS when the segment
+  // has at most kNmsLdsCap candidates (the usual tens to a few hundred), else in the global scratch p.sorted_boxes (LDS sized for
+  // every possible segment would leave 2 workgroups per CU)
   float4* qb = reinterpret_cast<float4*>(p.q_boxes) + (size_t)seg * p.R;
-  // the boxes again in SCORE order for the NMS below: in LDS when the segment has at most kNmsLdsCap candidates (the usual tens to
-  // a few hundred), else in the global scratch p.sorted_boxes -- LDS sized for every possible segment would leave 2 workgroups per CU
   float4* sbox_l = reinterpret_cast<float4*>(smem + (size_t)p.np2_max * sizeof(uint64_t));     // [kNmsLdsCap]
-  uint32_t* rank_of_q = reinterpret_cast<uint32_t*>(sbox_l + kNmsLdsCap);                        // [kNmsLdsCap] score rank of candidate q
+  float4* sorted_g = reinterpret_cast<float4*>(p.sorted_boxes) + (size_t)seg * p.R;
   const bool in_lds = n <= kNmsLdsCap;
-  if (in_lds) for (int k = tid; k < n; k += kDetThreads) rank_of_q[desc_key_index(keys[k])] = (uint32_t)k;
-  __syncthreads();
-  if (p.decoded) {          // lib/utils/result_utils.py:128: boxes[inds, j * 4:(j + 1) * 4] taken as they are
-    for (int q = tid; q < n; q += kDetThreads) {
-      const float* d = p.decoded + ((size_t)b * p.R + qroi[q]) * 4 * p.n_cls + 4 * j;
-      const float4 v = make_float4(d[0], d[1], d[2], d[3]);
-      qb[q] = v;
-      if (in_lds) sbox_l[rank_of_q[q]] = v;
-    }
-  }
   const float sf = p.decoded ? 1.f : p.scale[b];
   const float im_h = p.decoded ? 0.f : p.im_size[b * 2 + 0], im_w = p.decoded ? 0.f : p.im_size[b * 2 + 1];
-  for (int q = tid; q < n && !p.decoded; q += kDetThreads) {
-    const int r = qroi[q];
-    const float* roi = p.rois5 + ((size_t)b * p.R + r) * 5 + 1;
-    const float* d = p.bbox_pred + ((size_t)b * p.R + r) * 4 * p.n_cls + 4 * j;
-    const float rr[4] = {roi[0], roi[1], roi[2], roi[3]};
-    float o[4];
-    decode_det(rr, sf, d, p.wx, p.wy, p.ww, p.wh, im_h, im_w, o);
-    const float4 v = make_float4(o[0], o[1], o[2], o[3]);
-    qb[q] = v;                                             // candidate order (global, det_finalize)
-    if (in_lds) sbox_l[rank_of_q[q]] = v;                  // score order (LDS, the NMS)
+  for (int k = tid; k < n; k += kDetThreads) {
+    const int r = (int)desc_key_index(keys[k]);
+    float4 v;
+    if (p.decoded) {        // lib/utils/result_utils.py:128: boxes[inds, j * 4:(j + 1) * 4] taken as they are
+      const float* d = p.decoded + ((size_t)b * p.R + r) * 4 * p.n_cls + 4 * j;
+      v = make_float4(d[0], d[1], d[2], d[3]);
+    } else {
+      const float* roi = p.rois5 + ((size_t)b * p.R + r) * 5 + 1;
+      const float* d = p.bbox_pred + ((size_t)b * p.R + r) * 4 * p.n_cls + 4 * j;
+      const float rr[4] = {roi[0], roi[1], roi[2], roi[3]};
+      float o[4];
+      decode_det(rr, sf, d, p.wx, p.wy, p.ww, p.wh, im_h, im_w, o);
+      v = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    qb[r] = v;                                               // by roi index (global, det_finalize)
+    if (in_lds) sbox_l[k] = v; else sorted_g[k] = v;         // score order (the NMS)
   }
   __syncthreads();
   DTC_PT(0, ptb, 3);
@@ -193,7 +189,7 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
   // handful of classes, a very low score threshold or collect_top_n >> 2000 makes a class segment the critical path of the launch
   // (timing guard: tests/test_hip_fpn_det_mask.py::test_postprocess_crowded_classes_vs_oracle, R = 1500 x 3 classes).
   {
-    uint64_t* removed = reinterpret_cast<uint64_t*>(rank_of_q + kNmsLdsCap);                         // [(R + 63) / 64]
+    uint64_t* removed = reinterpret_cast<uint64_t*>(sbox_l + kNmsLdsCap);                            // [(R + 63) / 64]
     __shared__ uint32_t diag_s[kDetThreads / 64][64];
     __shared__ uint64_t keptm_s;
     __shared__ int kept_s;
@@ -222,11 +218,6 @@ __global__ __launch_bounds__(kDetThreads) void det_candidates_kernel(DetParams p
     };
     uint64_t* K = p.kept_key + (size_t)seg * p.R;
     const float4 pad = make_float4(0.f, 0.f, -1.f, -1.f);
-    float4* sorted_g = reinterpret_cast<float4*>(p.sorted_boxes) + (size_t)seg * p.R;
-    if (!in_lds) {          // a large segment: its boxes in score order through the global scratch
-      for (int k = tid; k < n; k += kDetThreads) sorted_g[k] = qb[(int)desc_key_index(keys[k])];
-      __syncthreads();
-    }
     auto run_blocks = [&](auto lds_tag) {
     const float4* sbox = decltype(lds_tag)::value ? static_cast<const float4*>(sbox_l) : static_cast<const float4*>(sorted_g);
     for (int rb = 0; rb < ncb; rb++) {
@@ -307,6 +298,7 @@ struct FinParams {
   int32_t* det_roi;           // [B, max_out]
   float* det_rois_scaled;     // [B, max_out, 4]  boxes * scaling_factor (eval_mask_FPN.ipynb:249), may be NULL
   int32_t* det_count;         // [B]
+  FpnMapOut fm;               // fm.on: also emit the FPN level mapping of the detection rows (the mask branch's rois), fpn_map.h
 };
 
 // off[c] = sum of cnt(c') for c' < c, c = 0 .. nseg (off[nseg] = total); one wavefront, nseg <= 256.
@@ -324,42 +316,80 @@ template <typename F> __device__ __forceinline__ void fin_prefix(int* off, F cnt
 }
 
 // kept entries staged in LDS (ordered score + candidate id, 8 bytes each): dynamic, sized by the launcher for the worst case the
-// arguments allow up to kFinStageMax (128 KB); more -> every pass re-fetches from global
-constexpr int kFinStageMax = 16384;
+// arguments allow up to kFinStageMax (112 KB); more -> every pass re-fetches from global
+constexpr int kFinStageMax = 14336;     // 112 KB dynamic + ~37 KB static
+
+constexpr int kFinSurvMax = 1024;    // survivors of the per-image limit the fast output path ranks by scanning (usual: ~100)
 
 __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p, int stage_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
   uint32_t* st_key = reinterpret_cast<uint32_t*>(fin_smem);             // [stage_cap] ordered score of kept entry f
-  uint32_t* st_cq = st_key + stage_cap;                                   // [stage_cap] candidate index q of kept entry f
-  __shared__ __attribute__((aligned(16))) uint32_t h[2048];
+  uint32_t* st_cq = st_key + stage_cap;                                   // [stage_cap] (class c << 12) | candidate index q of kept entry f
+  // one histogram per radix pass (11 + 11 + 10 bits), cleared once under the first global round trip: a pass is its atomics, one
+  // barrier and the digit selection -- not clear / barrier / atomics / barrier / select / barrier on ONE array (round 6: 15 -> 8 barriers)
+  __shared__ __attribute__((aligned(16))) uint32_t h0[2048], h1[2048], h2[1024];
   __shared__ uint32_t sh[2];
+  __shared__ int kcnt[kFinMaxCls];
   __shared__ int koff[kFinMaxCls + 1];
   __shared__ int ccnt[kFinMaxCls];
   __shared__ int coff[kFinMaxCls + 1];
   __shared__ uint64_t bitmap[kFinThreads / 64][64];  // per wave: up to 4096 candidates per class
+  __shared__ __attribute__((aligned(16))) uint32_t surv[kFinSurvMax + 4];
+  __shared__ int nsurv;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int NWV = kFinThreads / 64, kClsPerWave = kFinMaxCls / NWV;
   const int nseg = p.n_cls - 1;
   const int seg0 = b * nseg;
   DTC_PT(1, b, 0);
+  // Round 6: ONE global round trip in front of the LDS phases instead of three dependent ones (counts -> prefix -> binary search ->
+  // keys: 6 us of this kernel's 20).  Wave w owns classes w, w + 16, ...: it requests the class's kept count AND, speculatively, the
+  // first 64 kept keys of the class (the array is [S, R]: the addresses are valid whatever the count is; a class keeps a few dozen
+  // boxes) in the same breath; entries past 64 are fetched behind the prefix, the rare case.
+  int cnt_r[kClsPerWave];
+  uint64_t key_r[kClsPerWave];
+#pragma unroll
+  for (int k = 0; k < kClsPerWave; k++) {
+    const int c = wv + k * NWV;
+    cnt_r[k] = 0; key_r[k] = 0;
+    if (c < nseg) {
+      cnt_r[k] = p.keep_count[seg0 + c];
+      if (lane < p.R) key_r[k] = p.kept_key[(size_t)(seg0 + c) * p.R + lane];
+    }
+  }
+  if (tid == 0) nsurv = 0;
+  for (int i = tid; i < 2048; i += kFinThreads) { h0[i] = 0; h1[i] = 0; if (i < 1024) h2[i] = 0; }
+#pragma unroll
+  for (int k = 0; k < kClsPerWave; k++) { const int c = wv + k * NWV; if (c < kFinMaxCls && lane == 0) kcnt[c] = cnt_r[k]; }
+  __syncthreads();
   // exclusive prefix of the per-class kept counts: wavefront 0, four classes per lane (nseg <= kFinMaxCls = 256), shuffle scan
-  // -- a serial loop of thread 0 over 80 LDS words was 2 us of this kernel's 10 us prologue
-  if (wv == 0) fin_prefix(koff, [&](int c) { return c < nseg ? p.keep_count[seg0 + c] : 0; }, nseg, lane);
+  if (wv == 0) fin_prefix(koff, [&](int c) { return c < nseg ? kcnt[c] : 0; }, nseg, lane);
   __syncthreads();
   const int total = koff[nseg];
   const bool staged = total <= stage_cap;
-  // kept entry f of this image -> (ordered score, candidate index q, class c)
+  // kept entry e of class c of this image -> (ordered score, candidate index q)
   auto fetch = [&](int c, int e, uint32_t& o, int& q) {
     const uint64_t key = p.kept_key[(size_t)(seg0 + c) * p.R + e];
     q = (int)desc_key_index(key);
     o = ~(uint32_t)(key >> 32);                             // == float_to_ordered(q_scores[q]) (block_sort.h: make_desc_key)
   };
-  if (staged) {   // one global load per entry, paid once, in parallel; every later phase runs from LDS
-    for (int f = tid; f < total; f += kFinThreads) {
-      int lo = 0, hi = nseg;
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (koff[mid] <= f) lo = mid; else hi = mid; }
-      uint32_t o; int q;
-      fetch(lo, f - koff[lo], o, q);
-      st_key[f] = o; st_cq[f] = (uint32_t)q;
+  auto class_of = [&](int f) { int lo = 0, hi = nseg; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (koff[mid] <= f) lo = mid; else hi = mid; } return lo; };
+  if (staged) {   // every later phase runs from LDS
+#pragma unroll
+    for (int k = 0; k < kClsPerWave; k++) {
+      const int c = wv + k * NWV;
+      if (c >= nseg) continue;
+      const int n_c = cnt_r[k], base = koff[c];
+      if (lane < n_c) {
+        const uint32_t o = ~(uint32_t)(key_r[k] >> 32);
+        st_key[base + lane] = o; st_cq[base + lane] = ((uint32_t)c << 12) | desc_key_index(key_r[k]);
+        atomicAdd(&h0[o >> 21], 1u);                          // the first pass of the limit's radix select, while the entry is in hand
+      }
+      for (int e = 64 + lane; e < n_c; e += 64) {             // a crowded class: the rest of its entries, one more round trip
+        uint32_t o; int q;
+        fetch(c, e, o, q);
+        st_key[base + e] = o; st_cq[base + e] = ((uint32_t)c << 12) | (uint32_t)q;
+        atomicAdd(&h0[o >> 21], 1u);
+      }
     }
     __syncthreads();
   }
@@ -369,31 +399,81 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p, 
   if (p.max_det > 0 && total > p.max_det) {
     uint32_t prefix = 0, krem = (uint32_t)p.max_det;
     for (int pass = 0; pass < 3; pass++) {
-      for (int i = tid; i < 2048; i += kFinThreads) h[i] = 0;
-      __syncthreads();
-      for (int f = tid; f < total; f += kFinThreads) {
-        uint32_t o;
-        if (staged) o = st_key[f];
-        else {
-          int lo = 0, hi = nseg;
-          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (koff[mid] <= f) lo = mid; else hi = mid; }
-          int q; fetch(lo, f - koff[lo], o, q);
+      uint32_t* h = pass == 0 ? h0 : pass == 1 ? h1 : h2;
+      if (pass > 0 || !staged) {
+        for (int f = tid; f < total; f += kFinThreads) {
+          uint32_t o;
+          if (staged) o = st_key[f];
+          else { const int c = class_of(f); int q; fetch(c, f - koff[c], o, q); }
+          if (pass == 0) atomicAdd(&h[o >> 21], 1u);
+          else if (pass == 1) { if ((o >> 21) == prefix) atomicAdd(&h[(o >> 10) & 2047u], 1u); }
+          else { if ((o >> 10) == prefix) atomicAdd(&h[o & 1023u], 1u); }
         }
-        if (pass == 0) atomicAdd(&h[o >> 21], 1u);
-        else if (pass == 1) { if ((o >> 21) == prefix) atomicAdd(&h[(o >> 10) & 2047u], 1u); }
-        else { if ((o >> 10) == prefix) atomicAdd(&h[o & 1023u], 1u); }
+        __syncthreads();
       }
-      __syncthreads();
-      select_digit(h, pass == 2 ? 1024 : 2048, krem, sh);
+      select_digit(h, pass == 2 ? 1024 : 2048, krem, sh);      // ends with a barrier; sh is rewritten behind the next pass's barrier
       prefix = (prefix << (pass == 2 ? 10 : 11)) | sh[0];
       krem = sh[1];
-      __syncthreads();
     }
     T = prefix;
   }
-  // ---- pass A: survivors per class ----
   __syncthreads();
   DTC_PT(1, b, 2);
+  const float sf = p.scale ? p.scale[b] : 1.f;
+  float4* sbox_fm = reinterpret_cast<float4*>(&bitmap[0][0]);     // fast path + fm.on: the scaled boxes by output row (max_out <= 512)
+  auto emit = [&](int slot, int c, int q, bool to_lds) {      // one detection row (:143 dets_j[keep], :165 vstack)
+    const int seg = seg0 + c;
+    const float4 bx = reinterpret_cast<const float4*>(p.q_boxes)[(size_t)seg * p.R + q];
+    if (to_lds) sbox_fm[slot] = make_float4(bx.x * sf, bx.y * sf, bx.z * sf, bx.w * sf);
+    float* o = p.dets + ((size_t)b * p.max_out + slot) * 6;
+    o[0] = bx.x; o[1] = bx.y; o[2] = bx.z; o[3] = bx.w;
+    o[4] = p.q_scores[(size_t)seg * p.R + q];
+    o[5] = (float)(c + 1);
+    p.det_roi[(size_t)b * p.max_out + slot] = q;                               // the candidate index IS the roi index (round 6)
+    if (p.det_rois_scaled)
+      reinterpret_cast<float4*>(p.det_rois_scaled)[(size_t)b * p.max_out + slot] = make_float4(bx.x * sf, bx.y * sf, bx.z * sf, bx.w * sf);
+  };
+  // ---- fast output path (round 6): the survivors of the limit are ~100 rows.  They are appended to an LDS list in any order; the
+  // output row of a survivor is the number of survivors with a smaller (class, candidate) code -- class-major, candidate (= roi)
+  // ascending, exactly the reference's vstack order -- found by scanning the list with broadcast 16-byte reads; then ONE round of
+  // gathers.  (The per-class bitmap walk below paid five rounds of dependent loads per wave: 7 us.)
+  bool fast_done = false;
+  if (staged) {
+    for (int f = tid; f < total; f += kFinThreads) {
+      if (st_key[f] >= T) {                                                    // :161 `>=`
+        const int i = atomicAdd(&nsurv, 1);
+        if (i < kFinSurvMax) surv[i] = st_cq[f];
+      }
+    }
+    __syncthreads();
+    const int ns = nsurv;
+    if (ns <= kFinSurvMax) {
+      fast_done = true;
+      if (tid < 4) surv[ns + tid] = 0xffffffffu;                              // pad to a multiple of four: never smaller
+      if (tid == 0) p.det_count[b] = ns;
+      __syncthreads();
+      const int n4 = (ns + 3) >> 2;
+      for (int i = tid; i < ns; i += kFinThreads) {
+        const uint32_t me = surv[i];
+        int rank = 0;
+        for (int j = 0; j < n4; j++) {
+          const uint4 v = reinterpret_cast<const uint4*>(surv)[j];
+          rank += (v.x < me ? 1 : 0) + (v.y < me ? 1 : 0) + (v.z < me ? 1 : 0) + (v.w < me ? 1 : 0);
+        }
+        if (rank < p.max_out) emit(rank, (int)(me >> 12), (int)(me & 4095u), p.fm.on != 0);
+      }
+    }
+  }
+  if (fast_done) {
+    if (p.fm.on) {       // the mask branch's level mapping of these rows, here instead of in a launch of its own (round 6)
+      __syncthreads();
+      fpn_map_rows(p.fm, b, p.max_out, min(nsurv, p.max_out), [&](int t) { return sbox_fm[t]; }, h0, h1);
+    }
+    DTC_PT(1, b, 5);
+    return;
+  }
+  // ---- general path: more survivors than the list holds (max_det <= 0 on a large head, mass ties) or entries not staged ----
+  // pass A: survivors per class
   for (int c = wv; c < nseg; c += kFinThreads / 64) {
     const int nk = koff[c + 1] - koff[c];
     int cnt = 0;
@@ -418,9 +498,8 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p, 
   __syncthreads();
   DTC_PT(1, b, 4);
   // ---- pass B: class-major, candidate(roi)-ascending output (:143 dets_j[keep], :165 vstack) ----
-  const float sf = p.scale ? p.scale[b] : 1.f;
   for (int c = wv; c < nseg; c += kFinThreads / 64) {
-    const int seg = seg0 + c, nk = koff[c + 1] - koff[c];
+    const int nk = koff[c + 1] - koff[c];
     if (ccnt[c] == 0) continue;
     uint64_t* bm = bitmap[wv];
     bm[lane] = 0;
@@ -429,7 +508,7 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p, 
       const int e = e0 + lane;
       if (e < nk) {
         uint32_t o; int q;
-        if (staged) { o = st_key[koff[c] + e]; q = (int)st_cq[koff[c] + e]; } else fetch(c, e, o, q);
+        if (staged) { o = st_key[koff[c] + e]; q = (int)(st_cq[koff[c] + e] & 4095u); } else fetch(c, e, o, q);
         if (o >= T && q < 4096) atomicOr(reinterpret_cast<unsigned long long*>(&bm[q >> 6]), 1ull << (q & 63));
       }
     }
@@ -447,20 +526,18 @@ __global__ __launch_bounds__(kFinThreads) void det_finalize_kernel(FinParams p, 
       const int bit = __builtin_ctzll(w);
       w &= w - 1;
       const int q = lane * 64 + bit;
-      if (slot < p.max_out) {
-        const float4 bx = reinterpret_cast<const float4*>(p.q_boxes)[(size_t)seg * p.R + q];
-        float* o = p.dets + ((size_t)b * p.max_out + slot) * 6;
-        o[0] = bx.x; o[1] = bx.y; o[2] = bx.z; o[3] = bx.w;
-        o[4] = p.q_scores[(size_t)seg * p.R + q];
-        o[5] = (float)(c + 1);
-        p.det_roi[(size_t)b * p.max_out + slot] = p.q_roi[(size_t)seg * p.R + q];
-        if (p.det_rois_scaled)
-          reinterpret_cast<float4*>(p.det_rois_scaled)[(size_t)b * p.max_out + slot] =
-              make_float4(bx.x * sf, bx.y * sf, bx.z * sf, bx.w * sf);
-      }
+      if (slot < p.max_out) emit(slot, c, q, false);
       slot++;
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (p.fm.on) {         // general path: the rows come back from global memory (written by this workgroup: fence + barrier, uncached loads)
+    __threadfence();
+    __syncthreads();
+    const float* ds = p.det_rois_scaled + (size_t)b * p.max_out * 4;
+    auto ld = [&](const float* a) { return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    fpn_map_rows(p.fm, b, p.max_out, min(coff[nseg], p.max_out),
+                 [&](int t) { return make_float4(ld(ds + 4 * t), ld(ds + 4 * t + 1), ld(ds + 4 * t + 2), ld(ds + 4 * t + 3)); }, h0, h1);
   }
   DTC_PT(1, b, 5);
 }
@@ -498,8 +575,14 @@ static int postprocess_detections_impl(const float* rois5, const int32_t* n_rois
                                        int batch, int max_rois, int n_cls, float wx, float wy, float ww, float wh,
                                        float score_thresh, float nms_thresh, int max_det, void* workspace,
                                        size_t workspace_bytes, float* dets, int32_t* det_roi, float* det_rois_scaled,
-                                       int32_t* det_count, int max_out, dtc_stream_t stream) {
+                                       int32_t* det_count, int max_out, dtc_stream_t stream, const dtc_fpn_map_out* fpn = nullptr) {
   if (batch < 0 || max_rois < 1 || n_cls < 2 || n_cls - 1 > dtc::kFinMaxCls || max_out < 1) return DTC_EINVAL;
+  if (fpn) {
+    if (!det_rois_scaled || !fpn->rois5 || !fpn->roi_levels || !fpn->n_out || !fpn->rois_by_level || !fpn->level_counts || !fpn->idx_restore ||
+        fpn->k_max < fpn->k_min || fpn->k_max - fpn->k_min + 1 > 8)
+      return DTC_EINVAL;
+    if (max_out > dtc::kFpnMapMaxRows) return DTC_EUNSUPPORTED;      // longer lists: dtc_fpn_collect_distribute on det_rois_scaled
+  }
   if (batch == 0) return DTC_OK;
   if (max_rois > 4096) return DTC_EUNSUPPORTED;
   if (!cls_score || !workspace || !dets || !det_roi || !det_count) return DTC_EINVAL;
@@ -526,10 +609,9 @@ static int postprocess_detections_impl(const float* rois5, const int32_t* n_rois
   p.sorted_boxes = reinterpret_cast<float*>(w + pl.sorted_boxes);
   p.q_boxes = reinterpret_cast<float*>(w + pl.q_boxes); p.q_scores = reinterpret_cast<float*>(w + pl.q_scores);
   p.q_roi = reinterpret_cast<int32_t*>(w + pl.q_roi); p.cand_count = reinterpret_cast<int32_t*>(w + pl.cand_count);
-  // dynamic LDS: sort keys [next_pow2(R)] x 8 B, then up to kNmsLdsCap boxes in score order (16 B) + their ranks (4 B) and one
-  // removed-bit per candidate
+  // dynamic LDS: sort keys [next_pow2(R)] x 8 B, then up to kNmsLdsCap boxes in score order (16 B) and one removed-bit per candidate
   const int np2 = dtc::next_pow2(max_rois);
-  const size_t smem = (size_t)np2 * sizeof(uint64_t) + (size_t)dtc::kNmsLdsCap * (sizeof(float4) + sizeof(uint32_t)) +
+  const size_t smem = (size_t)np2 * sizeof(uint64_t) + (size_t)dtc::kNmsLdsCap * sizeof(float4) +
                       (size_t)((max_rois + 63) / 64) * sizeof(uint64_t);
   if (smem > 48 * 1024) { DTC_RAISE_LDS_ONCE(dtc::det_candidates_kernel, 152 * 1024); }
   uint64_t* kept_key = reinterpret_cast<uint64_t*>(w + pl.kept_key);
@@ -541,11 +623,18 @@ static int postprocess_detections_impl(const float* rois5, const int32_t* n_rois
   f.kept_key = kept_key; f.keep_count = keep_count; f.q_boxes = p.q_boxes; f.q_scores = p.q_scores;
   f.q_roi = p.q_roi; f.scale = scaling_factor; f.R = max_rois; f.n_cls = n_cls; f.max_det = max_det; f.max_out = max_out;
   f.dets = dets; f.det_roi = det_roi; f.det_rois_scaled = det_rois_scaled; f.det_count = det_count;
+  f.fm.on = fpn ? 1 : 0;
+  if (fpn) {
+    f.fm.rois5 = fpn->rois5; f.fm.roi_levels = fpn->roi_levels; f.fm.n_out = fpn->n_out; f.fm.rois_by_level = fpn->rois_by_level;
+    f.fm.level_counts = fpn->level_counts; f.fm.idx_restore = fpn->idx_restore; f.fm.roi_order = fpn->roi_order;
+    f.fm.roi_desc = fpn->roi_order ? fpn->roi_desc : nullptr; f.fm.k_min = fpn->k_min; f.fm.k_max = fpn->k_max;
+    f.fm.band_log2 = 4;                                               // as dtc_fpn_collect_distribute (fpn.hip)
+  }
   long long cap = (long long)max_rois * (n_cls - 1);            // every candidate of every class kept
   if (cap > dtc::kFinStageMax) cap = dtc::kFinStageMax;
   const int stage_cap = (int)((cap + 3) & ~3ll);
   const size_t fsm = (size_t)stage_cap * 8;
-  if (fsm > 32 * 1024) { DTC_RAISE_LDS_ONCE(dtc::det_finalize_kernel, 132 * 1024); }      // + ~18 KB static
+  if (fsm > 16 * 1024) { DTC_RAISE_LDS_ONCE(dtc::det_finalize_kernel, 116 * 1024); }      // + ~37 KB static: under the 160 KB of a CU
   hipLaunchKernelGGL(dtc::det_finalize_kernel, dim3(batch), dim3(dtc::kFinThreads), fsm, s, f, stage_cap);
   DTC_CHECK_LAUNCH();
   return DTC_OK;
@@ -571,6 +660,18 @@ DTC_API int dtc_postprocess_detections_logits(const float* rois5, const int32_t*
   return postprocess_detections_impl(rois5, n_rois, cls_logits, 1, bbox_pred, nullptr, scaling_factor, im_size, batch, max_rois, n_cls, wx,
                                      wy, ww, wh, score_thresh, nms_thresh, max_det, workspace, workspace_bytes, dets, det_roi,
                                      det_rois_scaled, det_count, max_out, stream);
+}
+
+DTC_API int dtc_postprocess_detections_fpn(const float* rois5, const int32_t* n_rois, const float* cls_score, int scores_are_logits,
+                                           const float* bbox_pred, const float* scaling_factor, const float* im_size,
+                                           int batch, int max_rois, int n_cls, float wx, float wy, float ww, float wh,
+                                           float score_thresh, float nms_thresh, int max_det, void* workspace,
+                                           size_t workspace_bytes, float* dets, int32_t* det_roi, float* det_rois_scaled,
+                                           int32_t* det_count, int max_out, const dtc_fpn_map_out* fpn, dtc_stream_t stream) {
+  if (!fpn) return DTC_EINVAL;
+  return postprocess_detections_impl(rois5, n_rois, cls_score, scores_are_logits ? 1 : 0, bbox_pred, nullptr, scaling_factor, im_size, batch,
+                                     max_rois, n_cls, wx, wy, ww, wh, score_thresh, nms_thresh, max_det, workspace, workspace_bytes, dets,
+                                     det_roi, det_rois_scaled, det_count, max_out, stream, fpn);
 }
 
 DTC_API int dtc_box_results_nms_limit(const float* scores, const float* boxes, const int32_t* n_rois, int batch, int max_rois,

@@ -11,21 +11,13 @@
 #include <mutex>
 
 #include "dtc_common.h"
+#include "fpn_map.h"
 
 namespace dtc {
 DTC_PT_TABLE(fpn)
 
 constexpr int kFpnThreads = 1024;
 constexpr int kFpnMaxLevels = 8;
-
-// lib/utils/multilevel_rois.py:47-52 in float32 numpy arithmetic (boxes_area: lib/utils/boxes.py:77-79)
-__device__ __forceinline__ int fpn_level(float x1, float y1, float x2, float y2, int k_min, int k_max) {
-  const float area = (x2 - x1 + 1.f) * (y2 - y1 + 1.f);
-  const float s = fsqrt(area);
-  float t = floorf(4.f + flog2_cr(fdiv(s, 224.f) + 1e-6f));
-  t = fminf(fmaxf(t, (float)k_min), (float)k_max);
-  return (int)t;
-}
 
 struct FpnParams {
   const float* in_boxes;     // [B, L_in, P, 4]
@@ -364,14 +356,7 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams
     // order key for the RoIAlign visiting order (see the general kernel): level | band | x, all in feature pixels
     const int r = rr * kFpnThreads + tid;
     key[rr] = 0xffffffffu;
-    if (r < p.top_n) {
-      const uint32_t yc = (uint32_t)fminf(fmaxf((bx[rr].y + bx[rr].w) * 0.5f, 0.f), 65535.f);
-      const uint32_t xc = (uint32_t)fminf(fmaxf((bx[rr].x + bx[rr].z) * 0.5f, 0.f), 65535.f);
-      const uint32_t lv4 = lvl[rr] < 0 ? 15u : (uint32_t)lvl[rr];
-      const uint32_t fs = min((uint32_t)p.k_min + lv4, 15u);
-      const uint32_t band = min((yc >> fs) >> p.band_log2, 63u), xf = min(xc >> fs, 4095u);
-      key[rr] = (min(lv4, 7u) << 29) | (((band << 12) | xf) << 11) | (uint32_t)r;   // r < 2048: 11 bits
-    }
+    if (r < p.top_n) key[rr] = fpn_order_key(bx[rr], lvl[rr], p.k_min, p.band_log2, r);
   }
   __syncthreads();                                                             // src_of_rank / sc reads done; wave_cnt complete
   if (tid < kOrderBuckets) { bstart[tid] = 0u; bcur[tid] = 0u; }

@@ -37,6 +37,13 @@ class FeatLevel(C.Structure):
                 ("stride_w", C.c_int64)]
 
 
+class FpnMapOut(C.Structure):
+    """struct dtc_fpn_map_out (include/detectorch_hip.h)"""
+    _fields_ = [("rois5", C.c_void_p), ("roi_levels", C.c_void_p), ("n_out", C.c_void_p), ("rois_by_level", C.c_void_p),
+                ("level_counts", C.c_void_p), ("idx_restore", C.c_void_p), ("roi_order", C.c_void_p), ("roi_desc", C.c_void_p),
+                ("k_min", C.c_int32), ("k_max", C.c_int32)]
+
+
 _lib = None
 
 
@@ -95,6 +102,9 @@ def lib():
     L.dtc_postprocess_detections.restype = i
     L.dtc_postprocess_detections_logits.argtypes = L.dtc_postprocess_detections.argtypes
     L.dtc_postprocess_detections_logits.restype = i
+    L.dtc_postprocess_detections_fpn.argtypes = [p, p, p, i, p, p, p, i, i, i, f, f, f, f, f, f, i, p, sz, p, p, p, p, i,
+                                                 C.POINTER(FpnMapOut), p]
+    L.dtc_postprocess_detections_fpn.restype = i
     L.dtc_box_results_nms_limit.argtypes = [p, p, p, i, i, i, f, f, i, p, sz, p, p, p, i, p]
     L.dtc_box_results_nms_limit.restype = i
     L.dtc_bias_act.argtypes = [p, p, p, i, i, i, i, i, i, i, i, p]

@@ -71,6 +71,11 @@ class FpnRegionPath:
         self.m_rois5, self.m_levels, self.m_n = e(B, D, 5), e(B, D, dtype=i32), e(B, dtype=i32)
         self.m_by_level, self.m_level_counts, self.m_restore = e(B, D, 4), e(B, 4, dtype=i32), e(B, D, dtype=i32)
         self.m_order, self.m_desc = e(B, D, dtype=i32), e(B, D, 8)
+        # the mask branch's level mapping comes out of the detection launch itself (dtc_postprocess_detections_fpn, <= 512 rows)
+        self.fused_mask_map = D <= 512
+        self.m_map = hip.FpnMapOut(self.m_rois5.data_ptr(), self.m_levels.data_ptr(), self.m_n.data_ptr(), self.m_by_level.data_ptr(),
+                                   self.m_level_counts.data_ptr(), self.m_restore.data_ptr(), self.m_order.data_ptr(),
+                                   self.m_desc.data_ptr(), 2, 5)
         self.mask_feats = e(B * D, self.C, self.mask_p, self.mask_p, dtype=self.feat_dtype)
         self.crops = torch.empty((B, self.crop_capacity), dtype=torch.uint8, device=dev)
         self.mask_boxes, self.mask_rects = torch.zeros((B, D, 4), dtype=i32, device=dev), torch.zeros((B, D, 4), dtype=i32, device=dev)
@@ -138,6 +143,15 @@ class FpnRegionPath:
         L, B, ck = hip.lib(), self.B, hip.check
         st = st or hip.stream_ptr(self.dev)
         T, D = self.top_n, self.max_out
+        if self.fused_mask_map:
+            ck(L.dtc_postprocess_detections_fpn(self.rois5.data_ptr(), self.n_rois.data_ptr(), self.cls_score.data_ptr(),
+                                                1 if self.cls_logits else 0, self.bbox_pred.data_ptr(), self.sf.data_ptr(),
+                                                self.im_size.data_ptr(), B, T, self.n_cls, 10.0, 10.0, 5.0, 5.0, 0.05, 0.5, self.max_det,
+                                                self.det_ws.data_ptr(), self.det_ws.numel(), self.dets.data_ptr(), self.det_roi.data_ptr(),
+                                                self.det_scaled.data_ptr(), self.det_count.data_ptr(), D, self.m_map, st),
+               "postprocess_detections_fpn")
+            self._roi_align_mask(st)
+            return
         post = L.dtc_postprocess_detections_logits if self.cls_logits else L.dtc_postprocess_detections
         ck(post(self.rois5.data_ptr(), self.n_rois.data_ptr(), self.cls_score.data_ptr(),
                 self.bbox_pred.data_ptr(), self.sf.data_ptr(), self.im_size.data_ptr(), B, T,

@@ -236,6 +236,24 @@ int dtc_postprocess_detections_logits(const float* rois5, const int32_t* n_rois,
                                       int32_t* det_roi, float* det_rois_scaled, int32_t* det_count, int max_out,
                                       dtc_stream_t stream);
 
+/* dtc_postprocess_detections[_logits] that ALSO emits the FPN level mapping of the detection rows for the mask branch
+ * (add_multilevel_rois_for_test, lib/utils/multilevel_rois.py:19-39; call site eval_mask_FPN.ipynb:249) -- what a following
+ * dtc_fpn_collect_distribute(det_rois_scaled, in_scores = NULL, det_count, batch, 1, max_out, max_out, k_min, k_max, ...) would
+ * write, bit for bit, without that launch (the workgroup that finalises an image's detections has its <= ~100 rows in hand).
+ * All of fpn's pointers are [B, max_out, ...] buffers as documented at dtc_fpn_collect_distribute (roi_order / roi_desc nullable);
+ * det_rois_scaled is required; max_out <= 512 (DTC_EUNSUPPORTED beyond: use the separate call). */
+typedef struct dtc_fpn_map_out {
+  float* rois5; int32_t* roi_levels; int32_t* n_out; float* rois_by_level; int32_t* level_counts; int32_t* idx_restore;
+  int32_t* roi_order; float* roi_desc;
+  int32_t k_min, k_max;
+} dtc_fpn_map_out;
+int dtc_postprocess_detections_fpn(const float* rois5, const int32_t* n_rois, const float* cls_score, int scores_are_logits,
+                                   const float* bbox_pred, const float* scaling_factor, const float* im_size, int batch,
+                                   int max_rois, int n_cls, float wx, float wy, float ww, float wh, float score_thresh,
+                                   float nms_thresh, int max_det, void* workspace, size_t workspace_bytes, float* dets,
+                                   int32_t* det_roi, float* det_rois_scaled, int32_t* det_count, int max_out,
+                                   const dtc_fpn_map_out* fpn, dtc_stream_t stream);
+
 /* box_results_with_nms_and_limit (hard NMS) of lib/utils/result_utils.py:96-168 on ALREADY decoded + clipped boxes, for a
  * batch, in one pass on the device (the reference: 80 Python iterations, each a host NMS call):
  *   scores [B,R,n_cls], boxes [B,R,4*n_cls] (class j in columns 4j..4j+3), n_rois int32 [B] (NULL: R).

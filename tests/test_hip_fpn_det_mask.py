@@ -542,3 +542,52 @@ def test_assemble_results_from_batched_path_equals_per_image_flow(hip, oracle):
             assert segms[j][b] == exp_segms[j][b], (j, b)
     recs = result_utils.coco_segm_results(boxes, segms, [11, 12], {j: j + 100 for j in range(81)})
     assert len(recs) == sum(min(int(c), path.max_out) for c in path.det_count.tolist())
+
+
+@pytest.mark.parametrize("D,max_det,logits", [(104, 100, False), (128, 100, True), (512, 0, False), (64, 100, False)])
+def test_postprocess_detections_fpn_equals_separate_mask_branch_mapping(hip, D, max_det, logits):
+    """dtc_postprocess_detections_fpn (round 6): the level mapping of the detection rows for the mask branch
+    (add_multilevel_rois_for_test, multilevel_rois.py:19-39) written by the detection launch itself must equal, buffer for buffer, what
+    dtc_postprocess_detections[_logits] + dtc_fpn_collect_distribute(in_scores = NULL) write -- including the padding rows, the
+    visiting order and the packed descriptors.  D = 512 with max_det = 0 (no limit: every kept box is a survivor) overflows the rows and
+    takes the general output path of det_finalize; D = 64 < 100 detections truncates."""
+    dev = torch.device("cuda", 0)
+    B, R, ncls = 3, 1000, 81
+    rs = synth.rng(8, 900 + D)
+    rois = np.stack([np.hstack([np.full((R, 1), b, np.float32), synth.make_rois(rs, R)]) for b in range(B)])
+    cls, deltas = zip(*[synth.make_head_outputs(rs, R) for _ in range(B)])
+    cls, deltas = np.stack(cls), np.stack(deltas)
+    if logits:
+        cls = np.log(np.maximum(cls, 1e-30)).astype(np.float32)
+    n_rois = torch.tensor([R, R - 37, 500], dtype=torch.int32, device=dev)
+    sf = torch.tensor([1.6, 1.25, 2.0], device=dev)
+    im = torch.tensor([[500.0, 833.0], [640.0, 480.0], [400.0, 600.0]], device=dev)
+    t_rois, t_cls, t_del = cu(rois), cu(cls), cu(deltas)
+    dets, det_roi, det_scaled, det_count = hip.postprocess_detections(t_rois, n_rois, t_cls, t_del, sf, im, max_det=max_det, max_out=D,
+                                                                       scores_are_logits=logits)
+    sep = hip.fpn_collect_distribute(det_scaled.view(B, 1, D, 4), None, det_count.view(B, 1), D)
+    L = hip.lib()
+    f32, i32 = torch.float32, torch.int32
+    e = lambda *s, dtype=f32: torch.full(s, -77, dtype=dtype, device=dev)
+    o = dict(rois5=e(B, D, 5), roi_levels=e(B, D, dtype=i32), n_out=e(B, dtype=i32), rois_by_level=e(B, D, 4), level_counts=e(B, 4, dtype=i32),
+             idx_restore=e(B, D, dtype=i32), roi_order=e(B, D, dtype=i32), roi_desc=e(B, D, 8))
+    fm = hip.FpnMapOut(o["rois5"].data_ptr(), o["roi_levels"].data_ptr(), o["n_out"].data_ptr(), o["rois_by_level"].data_ptr(),
+                       o["level_counts"].data_ptr(), o["idx_restore"].data_ptr(), o["roi_order"].data_ptr(), o["roi_desc"].data_ptr(), 2, 5)
+    ws = hip.workspace(L.dtc_postprocess_detections_workspace_bytes(B, R, ncls), dev)
+    d2, r2, s2, c2 = torch.zeros_like(dets), torch.zeros_like(det_roi), torch.zeros_like(det_scaled), torch.zeros_like(det_count)
+    hip.check(L.dtc_postprocess_detections_fpn(t_rois.data_ptr(), n_rois.data_ptr(), t_cls.data_ptr(), 1 if logits else 0, t_del.data_ptr(),
+                                               sf.data_ptr(), im.data_ptr(), B, R, ncls, 10.0, 10.0, 5.0, 5.0, 0.05, 0.5, max_det, ws.data_ptr(),
+                                               ws.numel(), d2.data_ptr(), r2.data_ptr(), s2.data_ptr(), c2.data_ptr(), D, fm, hip.stream_ptr(dev)),
+              "postprocess_detections_fpn")
+    torch.cuda.synchronize()
+    assert torch.equal(c2, det_count)
+    if D == 512:
+        assert int(det_count.max()) > D                          # the overflow case is really there
+    for b in range(B):
+        n = min(int(det_count[b]), D)
+        assert torch.equal(d2[b, :n], dets[b, :n]) and torch.equal(r2[b, :n], det_roi[b, :n]) and torch.equal(s2[b, :n], det_scaled[b, :n])
+        m = int(sep["n_out"][b])
+        assert int(o["n_out"][b]) == m == n
+        for k in ("rois5", "roi_levels", "idx_restore", "roi_order", "roi_desc", "level_counts"):
+            assert torch.equal(o[k][b], sep[k][b]), (k, b)
+        assert torch.equal(o["rois_by_level"][b, :m], sep["rois_by_level"][b, :m])
