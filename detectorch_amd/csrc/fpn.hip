@@ -26,6 +26,11 @@ struct FpnParams {
   int L_in, P, top_n, k_min, k_max;
   int band_log2;             // visiting-order band height in feature rows (log2)
   int inputs_sorted;         // every input list is already in (score desc) order (NMS output): merge by rank, no sort
+  // dtc_fpn_collect_distribute_kept (fast kernel only): in_boxes / in_scores are the SORTED pre-NMS arrays [B * L_in, k_stride, ...] and
+  // list l of image b is their rows keep[(b * L_in + l) * P + j], j < in_counts -- proposals[keep] of generate_proposals.py:119-120
+  // read in place instead of through a gather launch
+  const int32_t* keep;
+  int k_stride;
   float* rois5;              // [B, top_n, 5]   (b, x1, y1, x2, y2) in collected (score) order
   float* roi_scores;         // [B, top_n]      (may be NULL)
   int32_t* roi_levels;       // [B, top_n]      level - k_min, or -1 for rows >= n_out[b]
@@ -256,6 +261,7 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams
   uint32_t* bstart = reinterpret_cast<uint32_t*>(smem) + 2 * kTop;           // [512]   visiting order: bucket histogram -> start
   uint32_t* bcur = bstart + kOrderBuckets;                                   // [512]   members placed so far
   uint64_t* kbuf = reinterpret_cast<uint64_t*>(smem + fast_hdr_bytes(R));    // [n_max + (L_in - 1) * top_n] input keys, then merge outputs
+  int* kk_s = reinterpret_cast<int*>(kbuf + n_max + (p.L_in - 1) * p.top_n);   // [n_max] (keep form only) row of concat element i in its sorted segment
   __shared__ uint32_t bwsum[kOrderBuckets / 64];
   __shared__ int cnt_s[kFpnMaxLevels];
   __shared__ int l_off[kFpnMaxLevels], l_len[kFpnMaxLevels];
@@ -264,6 +270,37 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams
   const int nl_out = p.k_max - p.k_min + 1;
   DTC_PT(p.L_in > 1 ? 0 : 1, b, 0);
   if (tid < p.L_in) cnt_s[tid] = min(p.in_counts[b * p.L_in + tid], p.P);
+  // Round 6: the scores of EVERY row of every input list (n_max = L_in * P <= 8192: up to eight per thread) are requested before the
+  // lists' counts are known -- one global round trip in front of the merge instead of two dependent ones; rows past a count hold
+  // whatever the producer left there and are dropped when the keys are filed.  With `keep` a row is keep -> score: the index is
+  // clamped into the segment, so a stale index past the count cannot leave the array.
+  constexpr int kSpec = 8;
+  float sp_s[kSpec];
+  int sp_k[kSpec];
+  const bool spec = p.in_scores != nullptr && p.L_in > 1;
+  if (spec) {
+    // straight-line code (indices clamped, no branch per element): all index loads leave together, then all score loads
+    size_t row[kSpec];
+    const float rP = 1.0f / (float)p.P;
+#pragma unroll
+    for (int u = 0; u < kSpec; u++) {
+      const int idx = min(tid + u * kFpnThreads, n_max - 1);
+      const int l = (int)(((float)idx + 0.5f) * rP);                          // idx / P, exact: idx < 2^13, >= 0.5 / P from an integer
+      row[u] = ((size_t)b * p.L_in + l) * p.P + (idx - l * p.P);
+      sp_k[u] = 0;
+      if (p.keep) sp_k[u] = p.keep[row[u]];                                   // (uniform condition)
+    }
+#pragma unroll
+    for (int u = 0; u < kSpec; u++) {
+      if (p.keep) {
+        const int idx = min(tid + u * kFpnThreads, n_max - 1);
+        const int l = (int)(((float)idx + 0.5f) * rP);
+        sp_k[u] = min(max(sp_k[u], 0), p.k_stride - 1);
+        row[u] = ((size_t)b * p.L_in + l) * p.k_stride + sp_k[u];
+      }
+      sp_s[u] = p.in_scores[row[u]];
+    }
+  }
   __syncthreads();
   int in_off[kFpnMaxLevels + 1];
   in_off[0] = 0;
@@ -278,12 +315,19 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams
     // truncated to top_n.  Pairwise merge tree, every output found independently by a merge-path search on its diagonal
     // (<= 10 steps of two 8-byte LDS reads): round 1 merges (L0,L1) (L2,L3) ..., round 2 the results, ...  Keys are
     // (score desc, concat index asc) -- unique, so ties need no special case: the earlier level / earlier row wins (:95-97).
-    const float* scores = p.in_scores + (size_t)b * p.L_in * p.P;
-    for (int i = tid; i < n; i += kFpnThreads) {
-      int l = 0;
 #pragma unroll
-      for (int q = 1; q < kFpnMaxLevels; q++) if (q < p.L_in && i >= in_off[q]) l = q;
-      kbuf[i] = make_desc_key(scores[(size_t)l * p.P + (i - in_off[l])], (uint32_t)i);
+    for (int u = 0; u < kSpec; u++) {                                          // the speculative loads above, filed by concat index
+      const int idx = tid + u * kFpnThreads;
+      if (idx < n_max) {
+        const int l = (int)(((float)idx + 0.5f) * (1.0f / (float)p.P)), j = idx - l * p.P;
+        int off = 0, cnt = 0;
+#pragma unroll
+        for (int q = 0; q < kFpnMaxLevels; q++) if (q == l) { off = in_off[q]; cnt = in_off[q + 1] - in_off[q]; }
+        if (j < cnt) {
+          kbuf[off + j] = make_desc_key(sp_s[u], (uint32_t)(off + j));
+          if (p.keep) kk_s[off + j] = sp_k[u];
+        }
+      }
     }
     if (tid < p.L_in) { l_off[tid] = in_off[tid]; l_len[tid] = cnt_s[tid]; }
     __syncthreads();
@@ -341,8 +385,14 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams
       int l = 0;
 #pragma unroll
       for (int q = 1; q < kFpnMaxLevels; q++) if (q < p.L_in && src >= in_off[q]) l = q;
-      bx[rr] = reinterpret_cast<const float4*>(boxes)[(size_t)l * p.P + (src - in_off[l])];
-      if (p.in_scores) score[rr] = p.in_scores[((size_t)b * p.L_in + l) * p.P + (src - in_off[l])];
+      if (p.keep) {
+        const size_t row = ((size_t)b * p.L_in + l) * p.k_stride + kk_s[src];
+        bx[rr] = reinterpret_cast<const float4*>(p.in_boxes)[row];
+        score[rr] = p.in_scores[row];
+      } else {
+        bx[rr] = reinterpret_cast<const float4*>(boxes)[(size_t)l * p.P + (src - in_off[l])];
+        if (p.in_scores) score[rr] = p.in_scores[((size_t)b * p.L_in + l) * p.P + (src - in_off[l])];
+      }
       lvl[rr] = fpn_level(bx[rr].x, bx[rr].y, bx[rr].z, bx[rr].w, p.k_min, p.k_max) - p.k_min;
     }
   }
@@ -451,6 +501,46 @@ __global__ __launch_bounds__(kFpnThreads) void fpn_collect_fast_kernel(FpnParams
 
 }  // namespace dtc
 
+static int fpn_collect_launch(dtc::FpnParams p, int batch, long long n_max, dtc_stream_t stream) {
+  const int n_in_levels = p.L_in, post_nms_top_n = p.top_n, in_stride = p.P;
+  const float* in_scores = p.in_scores;
+  const int inputs_sorted = p.inputs_sorted;
+  size_t smem = in_scores ? (size_t)dtc::next_pow2((int)n_max) * sizeof(uint64_t) : 16;
+  if (in_scores && inputs_sorted) smem = (size_t)post_nms_top_n * sizeof(uint64_t) + (size_t)n_max * sizeof(float) + 16;
+  if (p.roi_order) { const size_t so = (size_t)(dtc::next_pow2(post_nms_top_n) < 4 ? 4 : dtc::next_pow2(post_nms_top_n)) * sizeof(uint64_t) * 2; if (so > smem) smem = so; }
+  if (post_nms_top_n > 16384) return DTC_EUNSUPPORTED;
+  static const bool no_fast = getenv("DTC_FPN_NO_FAST") != nullptr;     // A/B knob (general kernel), resolved once
+  const bool fast = post_nms_top_n <= dtc::kFastMaxTop && in_stride <= 1024 && n_max <= 8192 &&
+                    (!in_scores || inputs_sorted) && (!no_fast || p.keep);
+  if (fast) {
+    // k32 + src_of_rank + order buckets + input keys (n_max) + merge outputs (one top_n-strided list per pairwise merge:
+    // L - 1 of them): 8 B each; the keep form adds one int per input row
+    const int R = post_nms_top_n <= dtc::kFpnThreads ? 1 : 2;
+    const size_t fsm = (size_t)dtc::fast_hdr_bytes(R) +
+                       (size_t)(in_scores && n_in_levels > 1 ? n_max + (long long)(n_in_levels - 1) * post_nms_top_n : 0) * 8 +
+                       (p.keep ? (size_t)n_max * 4 : 0) + 16;
+    if (fsm <= 150 * 1024) {
+      if (R == 1) {
+        DTC_RAISE_LDS_ONCE(dtc::fpn_collect_fast_kernel<1>, 152 * 1024);
+        hipLaunchKernelGGL(dtc::fpn_collect_fast_kernel<1>, dim3(batch), dim3(dtc::kFpnThreads), fsm, reinterpret_cast<hipStream_t>(stream), p, (int)n_max);
+      } else {
+        DTC_RAISE_LDS_ONCE(dtc::fpn_collect_fast_kernel<2>, 152 * 1024);
+        hipLaunchKernelGGL(dtc::fpn_collect_fast_kernel<2>, dim3(batch), dim3(dtc::kFpnThreads), fsm, reinterpret_cast<hipStream_t>(stream), p, (int)n_max);
+      }
+      DTC_CHECK_LAUNCH();
+      return DTC_OK;
+    }
+  }
+  if (p.keep) return DTC_EUNSUPPORTED;         // the keep form exists in the fast kernel only: dtc_gather_kept + dtc_fpn_collect_distribute
+  if (smem > 32 * 1024) {   // static __shared__ of the kernel comes on top: raise the limit well before dynamic + static reaches 64 KB
+    DTC_RAISE_LDS_ONCE(dtc::fpn_collect_distribute_kernel, 144 * 1024);
+  }
+  hipLaunchKernelGGL(dtc::fpn_collect_distribute_kernel, dim3(batch), dim3(dtc::kFpnThreads), smem,
+                     reinterpret_cast<hipStream_t>(stream), p);
+  DTC_CHECK_LAUNCH();
+  return DTC_OK;
+}
+
 DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_scores, const int32_t* in_counts, int batch,
                                        int n_in_levels, int in_stride, int post_nms_top_n, int k_min, int k_max,
                                        float* rois5, float* roi_scores, int32_t* roi_levels, int32_t* n_out,
@@ -468,40 +558,32 @@ DTC_API int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_sc
   p.in_boxes = in_boxes; p.in_scores = in_scores; p.in_counts = in_counts; p.L_in = n_in_levels; p.P = in_stride;
   p.top_n = post_nms_top_n; p.k_min = k_min; p.k_max = k_max; p.inputs_sorted = inputs_sorted; p.rois5 = rois5; p.roi_scores = roi_scores;
   p.roi_levels = roi_levels; p.n_out = n_out; p.rois_by_level = rois_by_level; p.level_counts = level_counts;
+  p.keep = nullptr; p.k_stride = 0;
   // visiting-order band height (log2 feature rows): 16 rows suits the cluster-stationary RoIAlign kernel (clusters of ~5
   // neighbours stay ~28 rows x 32 pixels; measured 8 rows 0.48, 16 rows 0.41, 32 rows 0.43 ms per 8000-RoI box-head launch)
   p.band_log2 = 4;
   p.idx_restore = idx_restore; p.roi_order = roi_order; p.roi_desc = roi_order ? roi_desc : nullptr;
-  size_t smem = in_scores ? (size_t)dtc::next_pow2((int)n_max) * sizeof(uint64_t) : 16;
-  if (in_scores && inputs_sorted) smem = (size_t)post_nms_top_n * sizeof(uint64_t) + (size_t)n_max * sizeof(float) + 16;
-  if (roi_order) { const size_t so = (size_t)(dtc::next_pow2(post_nms_top_n) < 4 ? 4 : dtc::next_pow2(post_nms_top_n)) * sizeof(uint64_t) * 2; if (so > smem) smem = so; }
-  if (post_nms_top_n > 16384) return DTC_EUNSUPPORTED;
-  if (smem > 32 * 1024) {   // static __shared__ of the kernel comes on top: raise the limit well before dynamic + static reaches 64 KB
-    DTC_RAISE_LDS_ONCE(dtc::fpn_collect_distribute_kernel, 144 * 1024);
-  }
-  static const bool no_fast = getenv("DTC_FPN_NO_FAST") != nullptr;     // A/B knob (general kernel), resolved once
-  const bool fast = post_nms_top_n <= dtc::kFastMaxTop && in_stride <= 1024 && n_max <= 8192 &&
-                    (!in_scores || inputs_sorted) && !no_fast;
-  if (fast) {
-    // k32 + src_of_rank + order buckets + input keys (n_max) + merge outputs (one top_n-strided list per pairwise merge:
-    // L - 1 of them): 8 B each
-    const int R = post_nms_top_n <= dtc::kFpnThreads ? 1 : 2;
-    const size_t fsm = (size_t)dtc::fast_hdr_bytes(R) +
-                       (size_t)(in_scores && n_in_levels > 1 ? n_max + (long long)(n_in_levels - 1) * post_nms_top_n : 0) * 8 + 16;
-    if (fsm <= 150 * 1024) {
-      if (R == 1) {
-        DTC_RAISE_LDS_ONCE(dtc::fpn_collect_fast_kernel<1>, 152 * 1024);
-        hipLaunchKernelGGL(dtc::fpn_collect_fast_kernel<1>, dim3(batch), dim3(dtc::kFpnThreads), fsm, reinterpret_cast<hipStream_t>(stream), p, (int)n_max);
-      } else {
-        DTC_RAISE_LDS_ONCE(dtc::fpn_collect_fast_kernel<2>, 152 * 1024);
-        hipLaunchKernelGGL(dtc::fpn_collect_fast_kernel<2>, dim3(batch), dim3(dtc::kFpnThreads), fsm, reinterpret_cast<hipStream_t>(stream), p, (int)n_max);
-      }
-      DTC_CHECK_LAUNCH();
-      return DTC_OK;
-    }
-  }
-  hipLaunchKernelGGL(dtc::fpn_collect_distribute_kernel, dim3(batch), dim3(dtc::kFpnThreads), smem,
-                     reinterpret_cast<hipStream_t>(stream), p);
-  DTC_CHECK_LAUNCH();
-  return DTC_OK;
+  return fpn_collect_launch(p, batch, n_max, stream);
+}
+
+DTC_API int dtc_fpn_collect_distribute_kept(const float* sorted_boxes, const float* sorted_scores, int k_stride, const int32_t* keep,
+                                            const int32_t* keep_count, int keep_stride, int batch, int n_in_levels,
+                                            int post_nms_top_n, int k_min, int k_max, float* rois5, float* roi_scores,
+                                            int32_t* roi_levels, int32_t* n_out, float* rois_by_level, int32_t* level_counts,
+                                            int32_t* idx_restore, int32_t* roi_order, float* roi_desc, dtc_stream_t stream) {
+  if (batch < 0 || n_in_levels < 2 || n_in_levels > dtc::kFpnMaxLevels || keep_stride < 1 || k_stride < 1 || post_nms_top_n < 1 ||
+      k_max < k_min || k_max - k_min + 1 > dtc::kFpnMaxLevels)
+    return n_in_levels == 1 ? DTC_EUNSUPPORTED : DTC_EINVAL;
+  if (batch == 0) return DTC_OK;
+  if (!sorted_boxes || !sorted_scores || !keep || !keep_count || !rois5 || !roi_levels || !n_out || !rois_by_level || !level_counts ||
+      !idx_restore)
+    return DTC_EINVAL;
+  const long long n_max = (long long)n_in_levels * keep_stride;
+  dtc::FpnParams p;
+  p.in_boxes = sorted_boxes; p.in_scores = sorted_scores; p.in_counts = keep_count; p.L_in = n_in_levels; p.P = keep_stride;
+  p.top_n = post_nms_top_n; p.k_min = k_min; p.k_max = k_max; p.inputs_sorted = 1; p.rois5 = rois5; p.roi_scores = roi_scores;
+  p.roi_levels = roi_levels; p.n_out = n_out; p.rois_by_level = rois_by_level; p.level_counts = level_counts;
+  p.keep = keep; p.k_stride = k_stride; p.band_log2 = 4;
+  p.idx_restore = idx_restore; p.roi_order = roi_order; p.roi_desc = roi_order ? roi_desc : nullptr;
+  return fpn_collect_launch(p, batch, n_max, stream);
 }

@@ -89,6 +89,8 @@ def lib():
     L.dtc_gather_kept.restype = i
     ll = C.c_longlong
     L.dtc_fpn_collect_distribute.argtypes = [p, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p, i, p]
+    L.dtc_fpn_collect_distribute_kept.argtypes = [p, p, i, p, p, i, i, i, i, i, i, p, p, p, p, p, p, p, p, p, p]
+    L.dtc_fpn_collect_distribute_kept.restype = i
     L.dtc_roi_align_forward_packed.argtypes = [C.POINTER(FeatLevel), i, i, i, p, i, i, i, i, p, i, p]
     L.dtc_roi_align_forward_packed.restype = i
     L.dtc_roi_align_workspace_bytes.argtypes = [i]

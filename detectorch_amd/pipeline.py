@@ -55,7 +55,10 @@ class FpnRegionPath:
         self.pre_boxes, self.pre_scores, self.pre_counts = e(S, self.kmax, 4), e(S, self.kmax), e(S, dtype=i32)
         self.P = min(self.post, self.kmax)
         self.keep, self.keep_cnt = e(S, self.P, dtype=i32), e(S, dtype=i32)
-        self.prop_boxes, self.prop_scores = torch.zeros((S, self.P, 4), device=dev), torch.zeros((S, self.P), device=dev)
+        self._prop_boxes, self._prop_scores = torch.zeros((S, self.P, 4), device=dev), torch.zeros((S, self.P), device=dev)
+        # collect reads proposals[keep] in place (dtc_fpn_collect_distribute_kept) where its merge kernel holds the shape; otherwise the
+        # gather launch + the plain entry point
+        self.fused_gather = self.top_n <= 2048 and self.P <= 1024 and 5 * self.P <= 8192
         self.nms_ws = hip.workspace(L.dtc_nms_sorted_workspace_bytes(S, self.kmax), dev)
         T = self.top_n
         self.rois5, self.roi_scores = e(B, T, 5), e(B, T)
@@ -128,15 +131,42 @@ class FpnRegionPath:
         ck(L.dtc_nms_sorted(self.pre_boxes.data_ptr(), self.pre_counts.data_ptr(), S, self.kmax, self.rpn_thresh, self.P,
                             self.nms_ws.data_ptr(), self.nms_ws.numel(), self.keep.data_ptr(), self.P,
                             self.keep_cnt.data_ptr(), st), "nms_sorted")
-        ck(L.dtc_gather_kept(self.pre_boxes.data_ptr(), self.pre_scores.data_ptr(), S, self.kmax, self.keep.data_ptr(),
-                             self.keep_cnt.data_ptr(), self.P, self.prop_boxes.data_ptr(), self.prop_scores.data_ptr(), st),
-           "gather_kept")
-        ck(L.dtc_fpn_collect_distribute(self.prop_boxes.data_ptr(), self.prop_scores.data_ptr(), self.keep_cnt.data_ptr(),
-                                        B, 5, self.P, T, 2, 5, self.rois5.data_ptr(), self.roi_scores.data_ptr(),
-                                        self.roi_levels.data_ptr(), self.n_rois.data_ptr(), self.rois_by_level.data_ptr(),
-                                        self.level_counts.data_ptr(), self.idx_restore.data_ptr(),
-                                        self.roi_order.data_ptr(), self.roi_desc.data_ptr(), 1, st), "fpn_collect")
+        if self.fused_gather:
+            ck(L.dtc_fpn_collect_distribute_kept(self.pre_boxes.data_ptr(), self.pre_scores.data_ptr(), self.kmax, self.keep.data_ptr(),
+                                                 self.keep_cnt.data_ptr(), self.P, B, 5, T, 2, 5, self.rois5.data_ptr(),
+                                                 self.roi_scores.data_ptr(), self.roi_levels.data_ptr(), self.n_rois.data_ptr(),
+                                                 self.rois_by_level.data_ptr(), self.level_counts.data_ptr(), self.idx_restore.data_ptr(),
+                                                 self.roi_order.data_ptr(), self.roi_desc.data_ptr(), st), "fpn_collect_kept")
+        else:
+            self._gather_kept(st)
+            ck(L.dtc_fpn_collect_distribute(self._prop_boxes.data_ptr(), self._prop_scores.data_ptr(), self.keep_cnt.data_ptr(),
+                                            B, 5, self.P, T, 2, 5, self.rois5.data_ptr(), self.roi_scores.data_ptr(),
+                                            self.roi_levels.data_ptr(), self.n_rois.data_ptr(), self.rois_by_level.data_ptr(),
+                                            self.level_counts.data_ptr(), self.idx_restore.data_ptr(),
+                                            self.roi_order.data_ptr(), self.roi_desc.data_ptr(), 1, st), "fpn_collect")
         self._roi_align_box(st)
+
+    def _gather_kept(self, st=None):
+        st = st or hip.stream_ptr(self.dev)
+        hip.check(hip.lib().dtc_gather_kept(self.pre_boxes.data_ptr(), self.pre_scores.data_ptr(), self.B * 5, self.kmax, self.keep.data_ptr(),
+                                            self.keep_cnt.data_ptr(), self.P, self._prop_boxes.data_ptr(), self._prop_scores.data_ptr(), st),
+                  "gather_kept")
+
+    # per-level proposals after NMS (generate_proposals.py:119-120).  The fused step no longer materialises them (collect reads
+    # proposals[keep] in place); readers -- the parity checks -- get them from the gather kernel on demand.
+    @property
+    def prop_boxes(self):
+        if self.fused_gather:
+            with torch.cuda.device(self.dev):
+                self._gather_kept()
+        return self._prop_boxes
+
+    @property
+    def prop_scores(self):
+        if self.fused_gather:
+            with torch.cuda.device(self.dev):
+                self._gather_kept()
+        return self._prop_scores
 
     def launch_detections(self, st=None):
         """cls_score (probabilities, or logits with cls_logits=True) + bbox_pred -> dets -> mask-head features."""

@@ -202,6 +202,18 @@ int dtc_fpn_collect_distribute(const float* in_boxes, const float* in_scores, co
                                int32_t* level_counts, int32_t* idx_restore, int32_t* roi_order, float* roi_desc,
                                int inputs_sorted, dtc_stream_t stream);
 
+/* collect + distribute straight from the NMS output: list l of image b = rows keep[(b * L + l) * keep_stride + j], j < keep_count, of the
+ * score-sorted pre-NMS arrays sorted_boxes / sorted_scores [B * L, k_stride, ...] (what dtc_rpn_topk_decode and dtc_nms_sorted leave
+ * behind) -- proposals[keep], scores[keep] of generate_proposals.py:119-120 read in place, i.e. dtc_gather_kept +
+ * dtc_fpn_collect_distribute(inputs_sorted = 1) in one launch, the same outputs bit for bit.  2 <= n_in_levels; shapes the merge
+ * kernel does not hold (post_nms_top_n > 2048, keep_stride > 1024, n_in_levels * keep_stride > 8192) return DTC_EUNSUPPORTED: use the
+ * two calls. */
+int dtc_fpn_collect_distribute_kept(const float* sorted_boxes, const float* sorted_scores, int k_stride, const int32_t* keep,
+                                    const int32_t* keep_count, int keep_stride, int batch, int n_in_levels, int post_nms_top_n,
+                                    int k_min, int k_max, float* rois5, float* roi_scores, int32_t* roi_levels, int32_t* n_out,
+                                    float* rois_by_level, int32_t* level_counts, int32_t* idx_restore, int32_t* roi_order,
+                                    float* roi_desc, dtc_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * A8  Detection post-processing
  * --------------------------------------------------------------------------------------------------------------- */

@@ -591,3 +591,50 @@ def test_postprocess_detections_fpn_equals_separate_mask_branch_mapping(hip, D, 
         for k in ("rois5", "roi_levels", "idx_restore", "roi_order", "roi_desc", "level_counts"):
             assert torch.equal(o[k][b], sep[k][b]), (k, b)
         assert torch.equal(o["rois_by_level"][b, :m], sep["rois_by_level"][b, :m])
+
+
+@pytest.mark.parametrize("top_n,P", [(1000, 1000), (2000, 1000), (300, 640)])
+def test_collect_distribute_kept_equals_gather_then_collect(hip, top_n, P):
+    """dtc_fpn_collect_distribute_kept (round 6): collect reads proposals[keep] / scores[keep] (generate_proposals.py:119-120) in place
+    from the score-sorted pre-NMS arrays.  Every output buffer equal to dtc_gather_kept + dtc_fpn_collect_distribute(inputs_sorted = 1).
+    keep rows past a segment's count hold out-of-range garbage (the NMS leaves them untouched): must not be dereferenced out of bounds
+    or leak into the result.  Full, empty and single-element levels."""
+    dev = torch.device("cuda", 0)
+    B, L, K = 3, 5, 1300
+    rs = synth.rng(4, 700 + top_n)
+    S = B * L
+    sboxes = np.zeros((S, K, 4), np.float32)
+    sscores = np.zeros((S, K), np.float32)
+    for s_ in range(S):
+        sboxes[s_] = synth.make_rois(rs, K)
+        sscores[s_] = np.sort(synth.dedupe_scores(rs.uniform(0, 1, K).astype(np.float32)))[::-1]
+    counts = rs.randint(0, P + 1, (B, L)).astype(np.int32)
+    counts[1] = [P, P, P, P, min(P, 819)]
+    counts[2] = [3, 0, 0, 1, 0]
+    keep = rs.randint(-2 ** 31, 2 ** 31 - 1, (S, P)).astype(np.int32)          # garbage everywhere ...
+    for s_ in range(S):
+        c = int(counts.reshape(-1)[s_])
+        keep[s_, :c] = np.sort(rs.permutation(K)[:c])                         # ... but the kept positions (ascending = score order)
+    t_b, t_s, t_k, t_c = cu(sboxes), cu(sscores), cu(keep), cu(counts.reshape(-1))
+    L_ = hip.lib()
+    pb, ps = torch.zeros((S, P, 4), device=dev), torch.zeros((S, P), device=dev)
+    hip.check(L_.dtc_gather_kept(t_b.data_ptr(), t_s.data_ptr(), S, K, t_k.data_ptr(), t_c.data_ptr(), P, pb.data_ptr(), ps.data_ptr(),
+                                 hip.stream_ptr(dev)), "gather_kept")
+    ref = hip.fpn_collect_distribute(pb.view(B, L, P, 4), ps.view(B, L, P), t_c.view(B, L), top_n, 2, 5, inputs_sorted=True)
+    f32, i32 = torch.float32, torch.int32
+    e = lambda *s, dtype=f32: torch.full(s, -77, dtype=dtype, device=dev)
+    o = dict(rois5=e(B, top_n, 5), roi_scores=e(B, top_n), roi_levels=e(B, top_n, dtype=i32), n_out=e(B, dtype=i32),
+             rois_by_level=e(B, top_n, 4), level_counts=e(B, 4, dtype=i32), idx_restore=e(B, top_n, dtype=i32),
+             roi_order=e(B, top_n, dtype=i32), roi_desc=e(B, top_n, 8))
+    hip.check(L_.dtc_fpn_collect_distribute_kept(t_b.data_ptr(), t_s.data_ptr(), K, t_k.data_ptr(), t_c.data_ptr(), P, B, L, top_n, 2, 5,
+                                                 o["rois5"].data_ptr(), o["roi_scores"].data_ptr(), o["roi_levels"].data_ptr(),
+                                                 o["n_out"].data_ptr(), o["rois_by_level"].data_ptr(), o["level_counts"].data_ptr(),
+                                                 o["idx_restore"].data_ptr(), o["roi_order"].data_ptr(), o["roi_desc"].data_ptr(),
+                                                 hip.stream_ptr(dev)), "fpn_collect_distribute_kept")
+    torch.cuda.synchronize()
+    assert torch.equal(o["n_out"], ref["n_out"])
+    for b in range(B):
+        n = int(ref["n_out"][b])
+        for k in ("rois5", "roi_scores", "roi_levels", "idx_restore", "roi_order", "roi_desc", "level_counts"):
+            assert torch.equal(o[k][b], ref[k][b]), (k, b)
+        assert torch.equal(o["rois_by_level"][b, :n], ref["rois_by_level"][b, :n])
