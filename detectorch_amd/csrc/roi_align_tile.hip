@@ -296,6 +296,71 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
     }
   };
 
+#ifdef DTC_TILE_REPLAY
+  // Development aid (tools/r06/replay.sh, round 6: VERDICT r05 item 5): the shipped launch's exact work order with only ONE of its
+  // three streams left in -- same workgroups, same clusters, same passes, same addresses.  Compiled out of the product.
+  //   1  staging loads only (no LDS commit, no pooling, no stores, no barriers): the loads are consumed by an XOR that is never stored
+  //   4  loads + commit + the two barriers per pass (no pooling, no stores)
+  //   2  pooled-slab stores only (the slab holds whatever LDS held; no loads, no commit, no pooling, no barriers)
+  //   3  pooling only, from the LDS image as it is (no loads, no commit, no stores; both barriers per pass)
+  {
+    uint32_t sink = 0;
+    if (DTC_TILE_REPLAY == 1 || DTC_TILE_REPLAY == 4) { if (vec) issue(0); }
+    int cs_prev = 0, nq_prev = 0;
+#pragma unroll 1
+    for (int qs = 0; qs < nq_tot; qs += nq_pass) {
+      const int cs = 4 * qs;
+      const int nq_cur = min(nq_pass, nq_tot - qs);
+      if (DTC_TILE_REPLAY == 1) {
+#pragma unroll
+        for (int u = 0; u < U; u++) { if constexpr (L16) sink ^= v[u].x ^ v[u].y; else sink ^= __float_as_uint(v[u].x) ^ __float_as_uint(v[u].w); }
+        if (vec && qs + nq_pass < nq_tot) issue(cs + 4 * nq_pass);
+      } else if (DTC_TILE_REPLAY == 4) {
+        if (vec) commit(); else stage_scalar(cs);
+        __syncthreads();
+        if (vec && qs + nq_pass < nq_tot) issue(cs + 4 * nq_pass);
+        __syncthreads();
+      } else if (DTC_TILE_REPLAY == 2) {
+        store_slab(cs, nq_cur);
+      } else if (DTC_TILE_REPLAY == 3) {
+        __syncthreads();
+        if (it.on) {
+          float* so = slab + rl * (4 * nq_cur * bins) + bin;
+#pragma unroll 1
+          for (int q = 0; q < nq_cur; q++) {
+            const char* wq = reinterpret_cast<const char*>(win) + uni(q * plane * SB);
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+            for (int iy = 0; iy < 2; iy++) {
+              if constexpr (!L16) {
+                f32x4 t[2][4];
+#pragma unroll
+                for (int ix = 0; ix < 2; ix++)
+#pragma unroll
+                  for (int k = 0; k < 4; k++) t[ix][k] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(wq + it.a[iy][ix][k], 16));
+#pragma unroll
+                for (int ix = 0; ix < 2; ix++) {
+                  const float w1 = it.yh[iy] * it.xh[ix], w2 = it.yh[iy] * it.xl[ix], w3 = it.yl[iy] * it.xh[ix], w4 = it.yl[iy] * it.xl[ix];
+                  a01 += w1 * t[ix][0].lo + w2 * t[ix][1].lo + w3 * t[ix][2].lo + w4 * t[ix][3].lo;
+                  a23 += w1 * t[ix][0].hi + w2 * t[ix][1].hi + w3 * t[ix][2].hi + w4 * t[ix][3].hi;
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            float* o = so + uni(4 * q * bins);
+            o[0] = a01.x * 0.25f; o[bins] = a01.y * 0.25f; o[2 * bins] = a23.x * 0.25f; o[3 * bins] = a23.y * 0.25f;
+          }
+        }
+        __syncthreads();
+      }
+      cs_prev = cs; nq_prev = nq_cur;
+    }
+    (void)cs_prev; (void)nq_prev;
+    if (sink == 0x9e3779b9u && p.n_rois < 0) reinterpret_cast<uint32_t*>(p.out)[0] = sink;     // never true: keeps the loads alive
+  }
+  TT_MARK(10);
+}
+#else
   TT_MARK(3);
   if (vec) issue(0);
   int cs_prev = 0, nq_prev = 0;
@@ -390,6 +455,8 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
   if (nq_prev) store_slab(cs_prev, nq_prev);   // the next cluster writes the slab only behind its own first barrier
   TT_MARK(10);
 }
+#endif
+
 
 // Work item of block b: XCD x (= b % 8) owns a contiguous slice of the (cluster group, channel block) items, as in
 // xcd_work_item, but walks it BACK TO FRONT: the visiting order ends with the coarsest level of an image, whose RoIs have the
