@@ -86,6 +86,71 @@ __device__ __forceinline__ void n16_pool_bin(const N16Tab& y0e, const N16Tab& y1
   }
 }
 
+// CONTRACT mode on 16-bit maps (dtc_roi_align_set_exact(0)): the 16 taps of a bin share pixels whenever its two samples per axis are
+// less than a pixel apart (bins under 2 px: the small RoIs that fill P2 -- 94 % of the bench's proposals): sample 1's low row IS
+// sample 0's low or high row, and so for the columns; 4-9 distinct pixels instead of 16.  The direct-gather kernel is bound by the
+// texture data path (16 x 16 B per lane and bin through a 64 B/clk return path, TD 83 % busy), so here every DISTINCT pixel is
+// requested once: per axis the four (offset, weight) entries are merged where the offsets coincide (weights summed -- bilinear weights
+// are separable, sum of products == product of sums in exact arithmetic, a few float32 ulp apart in float32: inside the 1e-4 contract,
+// not bit-identical, hence contract mode only), a pixel (row entry i, column entry j) is loaded by the lanes whose entries i and j
+// are both live, and the 8 fused multiply-accumulates of a pixel are skipped by a wavefront in which no lane holds it (entry 2 of an
+// axis is never live for bins under 2 px: 7 of the 16 combinations).
+struct N16Rec { uint32_t off[4]; float w[4]; };      // one bin row / column, merged: bit 0 of off[1..3] = entry is live (offsets are multiples of 16)
+__device__ __forceinline__ N16Rec n16_merge_axis(const N16Tab& e0, const N16Tab& e1) {
+  uint32_t off[4] = {e0.lo, e0.hi, e1.lo, e1.hi};
+  float w[4] = {e0.h, e0.l, e1.h, e1.l};
+  bool live[4];
+  live[0] = true;
+  live[1] = off[1] != off[0];                           // clamped at the last row / column: lo == hi
+  if (!live[1]) w[0] += w[1];
+#pragma unroll
+  for (int k = 2; k < 4; k++) {
+    live[k] = true;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (j < k && live[k] && live[j] && off[k] == off[j]) { w[j] += w[k]; live[k] = false; }
+    }
+  }
+  N16Rec r;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { r.off[k] = off[k] | (k && live[k] ? 1u : 0u); r.w[k] = w[k]; }
+  return r;
+}
+
+template <typename TIn, typename TOut, typename LD>
+__device__ __forceinline__ void n16_pool_bin_shared(const N16Rec& ya, const N16Rec& xa, LD ld, TOut* so, int bins) {
+  bool ly[4], lx[4];
+  uint32_t oy[4], ox[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { ly[k] = k == 0 || (ya.off[k] & 1u); lx[k] = k == 0 || (xa.off[k] & 1u); oy[k] = ya.off[k] & ~1u; ox[k] = xa.off[k] & ~1u; }
+  uint4 t[16];              // a lane's t[4 i + j] is defined (and read) only where its entries i and j are both live
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (ly[i] && lx[j]) t[4 * i + j] = ld(oy[i], ox[j]);                      // only the lanes that hold this pixel request it
+  __builtin_amdgcn_sched_barrier(0);
+  f32x2 a[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) a[k] = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (ly[i] && lx[j]) {                                                     // (a wavefront without such a lane skips the block)
+        const float w = ya.w[i] * xa.w[j];
+        const uint32_t* u = reinterpret_cast<const uint32_t*>(&t[4 * i + j]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) fma_pair16<TIn>(a[k], u[k], w);
+      }
+    }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const f32x2 o = a[k] * 0.25f;
+    n16_put<TOut>(so + (2 * k) * bins, o.x); n16_put<TOut>(so + (2 * k + 1) * bins, o.y);
+  }
+}
+
 // CB: channels per workgroup (64, or 32 when a 64-channel slab of one RoI exceeds the budget: 14 x 14 bins with float32 output)
 template <typename TIn, typename TOut, int CB, bool FUSED>
 // (98 VGPRs: four workgroups per CU; bounding it to five -- 96 VGPRs -- measured no difference and spilled the bf16 variants)
@@ -105,8 +170,43 @@ __global__ __launch_bounds__(kN16Threads) void roi_align_fwd_nhwc16(RoiAlignPara
   const int ri0 = grp * G;
   const int ng = min(G, p.n_rois - ri0);
 
+  constexpr bool SHARED = FUSED && sizeof(TIn) == 2;       // contract mode on 16-bit maps: merged bin rows / columns (N16Rec) instead of per-sample entries
+  const int nrec = p.pooled_h + p.pooled_w;
+  N16Rec* recs = reinterpret_cast<N16Rec*>(tabs);            // the same bytes: ne entries of 16 B == nrec records of 32 B
   // ---- A. axis tables of the group's RoIs: thread <-> (RoI, table entry); entry 0's thread also files the RoI ----------------
-  for (int t = tid; t < ng * ne; t += kN16Threads) {
+  for (int t = tid; t < ng * (SHARED ? nrec : ne); t += kN16Threads) {
+    if constexpr (SHARED) {
+      const int rl = t / nrec, e = t - rl * nrec;
+      const RoiHead hd = load_roi_head(p, ri0 + rl);
+      N16Rec rec;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { rec.off[k] = 0u; rec.w[k] = 0.f; }
+      N16Roi info; info.r = hd.r; info.lvl = -1; info.rebase = 0u; info.far = 0u; info.ptr = base0;
+      if (hd.lvl >= 0 && hd.lvl < p.n_levels) {
+        const dtc_feat_level& L = p.lv[hd.lvl];
+        const bool isy = e < p.pooled_h;
+        const int u = isy ? e : e - p.pooled_h;
+        const uint32_t sb = (uint32_t)ESZ * (uint32_t)(isy ? L.stride_h : L.stride_w);
+        N16Tab o2[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          const AxisEntry a = isy ? make_axis(hd.sh, hd.bin_h, u, i, 2, L.height) : make_axis(hd.sw, hd.bin_w, u, i, 2, L.width);
+          o2[i].lo = (uint32_t)a.lo * sb; o2[i].hi = (uint32_t)a.hi * sb; o2[i].l = a.l; o2[i].h = a.h;
+        }
+        rec = n16_merge_axis(o2[0], o2[1]);
+        if (e == 0) {
+          const char* img = reinterpret_cast<const char*>(L.data) + ESZ * (int64_t)hd.b * L.stride_n;
+          const uint64_t delta = (uint64_t)(img - base0);
+          const uint64_t ext = (uint64_t)ESZ * ((uint64_t)L.stride_h * (uint64_t)L.height + (uint64_t)L.stride_w * (uint64_t)L.width + (uint64_t)p.channels);
+          info.lvl = hd.lvl; info.ptr = img;
+          info.far = (delta + ext) >= (1ull << 32) ? 1u : 0u;
+          info.rebase = (uint32_t)delta;
+        }
+      }
+      recs[t] = rec;
+      if (e == 0) rinfo[rl] = info;
+      continue;
+    }
     const int rl = t / ne, e = t - rl * ne;
     const RoiHead hd = load_roi_head(p, ri0 + rl);
     N16Tab o; o.lo = o.hi = 0u; o.l = o.h = 0.f;
@@ -151,7 +251,10 @@ __global__ __launch_bounds__(kN16Threads) void roi_align_fwd_nhwc16(RoiAlignPara
     constexpr bool FAR = decltype(far_tag)::value;
     for (int it = slot; it < items; it += kStep) {
       const N16Tab* tab = tabs + rl * ne;
-      const N16Tab y0e = tab[2 * ph], y1e = tab[2 * ph + 1], x0e = tab[ny + 2 * pw], x1e = tab[ny + 2 * pw + 1];
+      N16Tab y0e, y1e, x0e, x1e;
+      N16Rec yr, xr;
+      if constexpr (SHARED) { yr = recs[rl * nrec + ph]; xr = recs[rl * nrec + p.pooled_h + pw]; }
+      else { y0e = tab[2 * ph]; y1e = tab[2 * ph + 1]; x0e = tab[ny + 2 * pw]; x1e = tab[ny + 2 * pw + 1]; }
       const N16Roi info = rinfo[rl];
       TOut* so = slab + ((size_t)rl * CB + CPL * q8) * bins + (ph * p.pooled_w + pw);
       if (info.lvl < 0) {            // padding row of a fixed-shape batch: defined output
@@ -159,10 +262,12 @@ __global__ __launch_bounds__(kN16Threads) void roi_align_fwd_nhwc16(RoiAlignPara
         for (int k = 0; k < CPL; k++) n16_put<TOut>(so + k * bins, 0.f);
       } else if constexpr (FAR) {
         const char* lbase = info.ptr + ESZ * c0 + lane_off;
-        n16_pool_bin<TIn, TOut, FUSED>(y0e, y1e, x0e, x1e, [&](uint32_t yo, uint32_t xo) { return *reinterpret_cast<const uint4*>(lbase + (yo + xo)); }, so, bins);
+        if constexpr (SHARED) n16_pool_bin_shared<TIn, TOut>(yr, xr, [&](uint32_t yo, uint32_t xo) { return *reinterpret_cast<const uint4*>(lbase + (yo + xo)); }, so, bins);
+        else n16_pool_bin<TIn, TOut, FUSED>(y0e, y1e, x0e, x1e, [&](uint32_t yo, uint32_t xo) { return *reinterpret_cast<const uint4*>(lbase + (yo + xo)); }, so, bins);
       } else {
         const uint32_t lo = info.rebase + lane_off;
-        n16_pool_bin<TIn, TOut, FUSED>(y0e, y1e, x0e, x1e, [&](uint32_t yo, uint32_t xo) { return *reinterpret_cast<const uint4*>(sbase + (yo + lo + xo)); }, so, bins);
+        if constexpr (SHARED) n16_pool_bin_shared<TIn, TOut>(yr, xr, [&](uint32_t yo, uint32_t xo) { return *reinterpret_cast<const uint4*>(sbase + (yo + lo + xo)); }, so, bins);
+        else n16_pool_bin<TIn, TOut, FUSED>(y0e, y1e, x0e, x1e, [&](uint32_t yo, uint32_t xo) { return *reinterpret_cast<const uint4*>(sbase + (yo + lo + xo)); }, so, bins);
       }
       pw += step_w; if (pw >= p.pooled_w) { pw -= p.pooled_w; ph++; }
       ph += step_h; if (ph >= p.pooled_h) { ph -= p.pooled_h; rl++; }

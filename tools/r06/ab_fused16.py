@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--top-n", type=int, default=2000)
+    ap.add_argument("--mode", choices=["ab", "exact", "contract"], default="ab", help="ab: both modes interleaved; exact / contract: only that mode (counter runs)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     fdt = torch.bfloat16 if a.bf16 else torch.float16
@@ -41,6 +42,10 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / a.iters
 
+    if a.mode != "ab":
+        hip.roi_align_set_exact(a.mode == "exact")
+        print("%s: %.4f ms" % (a.mode, timed()))
+        return
     res = {0: [], 1: []}
     feats = {}
     for _ in range(a.rounds):
