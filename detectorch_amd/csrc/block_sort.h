@@ -26,6 +26,37 @@ __device__ __forceinline__ float desc_key_score(uint64_t k) { return ordered_to_
 __device__ __forceinline__ uint32_t desc_key_index(uint64_t k) { return (uint32_t)k; }
 constexpr uint64_t kPadKey = ~0ull;
 
+// value of lane (lane ^ J) for a COMPILE-TIME distance J < 64.  J = 1, 2, 4, 8 are DPP moves on the VALU (quad_perm / row_mirror /
+// row_half_mirror: ~8 cycles); 16 is a ds_swizzle, 32 a ds_bpermute (both through the LDS crossbar, ~100+ cycles) -- the run-time
+// distance of __shfl_xor is always the latter.  34 of the 45 wave-local steps of a 1024-key sort, 18 of the 21 of a 64-key sort, are
+// distances 1-8.  Every lane of the wavefront must be active.
+template <int J> __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+  const int x = (int)v;
+  if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);            // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);       // quad_perm [2,3,0,1]
+  else if constexpr (J == 4) {                                                                                 // (l ^ 7) ^ 3
+    const int t = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);                                   // row_half_mirror
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xf, 0xf, false);                                 // quad_perm [3,2,1,0]
+  } else if constexpr (J == 8) {                                                                               // (l ^ 15) ^ 7
+    const int t = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false);                                   // row_mirror
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x141, 0xf, 0xf, false);                                // row_half_mirror
+  } else if constexpr (J == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle(x, 0x401F);                       // bit mode: xor 0x10, and 0x1f
+  else return (uint32_t)__shfl_xor(x, J, 64);
+}
+
+// one compare-exchange step of distance J < 64 on the register-resident keys (see block_bitonic_sort_regs)
+template <int J, int THREADS, int E>
+__device__ __forceinline__ void bitonic_wave_step(uint64_t (&v)[E], int tid, int k) {
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int idx = e * THREADS + tid;
+    const uint32_t lo = lane_xor<J>((uint32_t)v[e]), hi = lane_xor<J>((uint32_t)(v[e] >> 32));
+    const uint64_t o = ((uint64_t)hi << 32) | lo;
+    const bool take_min = ((idx & J) == 0) == ((idx & k) == 0);
+    v[e] = take_min ? (o < v[e] ? o : v[e]) : (o > v[e] ? o : v[e]);
+  }
+}
+
 // Sort keys[0..n_pow2) ascending.  n_pow2 is a power of two >= 2, <= 16 * THREADS; every thread of the block must call.
 //
 // The keys live in REGISTERS during the sort: thread t holds elements e * THREADS + t (E = n_pow2 / THREADS of them, one when
@@ -73,15 +104,14 @@ __device__ __forceinline__ void block_bitonic_sort_regs(uint64_t* keys, int n_po
             v[e] = take_min ? (o < v[e] ? o : v[e]) : (o > v[e] ? o : v[e]);
           }
         }
-      } else {                                             // partner in this wave
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-          const int idx = e * THREADS + tid;
-          const uint32_t lo = __shfl_xor((uint32_t)v[e], j, 64), hi = __shfl_xor((uint32_t)(v[e] >> 32), j, 64);
-          const uint64_t o = ((uint64_t)hi << 32) | lo;
-          const bool take_min = ((idx & j) == 0) == ((idx & k) == 0);
-          v[e] = take_min ? (o < v[e] ? o : v[e]) : (o > v[e] ? o : v[e]);
-        }
+      } else {                                             // partner in this wave: the rest of the stage, compile-time distances
+        if (j >= 32) bitonic_wave_step<32, THREADS, E>(v, tid, k);
+        if (j >= 16) bitonic_wave_step<16, THREADS, E>(v, tid, k);
+        if (j >= 8) bitonic_wave_step<8, THREADS, E>(v, tid, k);
+        if (j >= 4) bitonic_wave_step<4, THREADS, E>(v, tid, k);
+        if (j >= 2) bitonic_wave_step<2, THREADS, E>(v, tid, k);
+        bitonic_wave_step<1, THREADS, E>(v, tid, k);
+        break;
       }
     }
   }
@@ -91,11 +121,57 @@ __device__ __forceinline__ void block_bitonic_sort_regs(uint64_t* keys, int n_po
   __syncthreads();
 }
 
+// One key per thread, 256 <= n_pow2 <= THREADS: every wavefront sorts its 64 keys in registers (the 21 wave-local steps of the network,
+// ascending in every wave), then log2(n / 64) MERGE rounds through the LDS array -- every thread finds ITS output of the merge of two
+// sorted runs by a merge-path search (<= log2(run) + 1 steps of two 8-byte LDS reads), two barriers per round.  A 1024-key sort: 21 + 4
+// rounds instead of the network's 21 + 24 wave-local steps + 10 LDS exchanges with two barriers each (rpn_sort: 8.7 -> see tools/r06).
+// Equal keys only occur as padding (kPadKey, sorted last): their mutual order is immaterial.
+template <int THREADS>
+__device__ __forceinline__ void block_merge_sort_e1(uint64_t* keys, int n_pow2) {
+  const int tid = threadIdx.x;
+  uint64_t v[1];
+  v[0] = tid < n_pow2 ? keys[tid] : kPadKey;
+  constexpr int kUp = 1 << 30;                             // (idx & kUp) == 0 for every idx: the last stage sorts every wave ascending
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+    const int kk = k == 64 ? kUp : k;
+    if (k >= 64) bitonic_wave_step<32, THREADS, 1>(v, tid, kk);
+    if (k >= 32) bitonic_wave_step<16, THREADS, 1>(v, tid, kk);
+    if (k >= 16) bitonic_wave_step<8, THREADS, 1>(v, tid, kk);
+    if (k >= 8) bitonic_wave_step<4, THREADS, 1>(v, tid, kk);
+    if (k >= 4) bitonic_wave_step<2, THREADS, 1>(v, tid, kk);
+    bitonic_wave_step<1, THREADS, 1>(v, tid, kk);
+  }
+  for (int run = 64; run < n_pow2; run <<= 1) {
+    __syncthreads();                                       // the previous round's reads are done
+    if (tid < n_pow2) keys[tid] = v[0];
+    __syncthreads();
+    if (tid < n_pow2) {
+      const int k = tid & (2 * run - 1);
+      const uint64_t* A = keys + (tid - k);
+      const uint64_t* B = A + run;
+      int lo = max(0, k - run), hi = min(k, run);          // i = number of elements taken from A among the first k outputs
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (A[mid] < B[k - mid - 1]) lo = mid + 1; else hi = mid;
+      }
+      const int i = lo, j = k - lo;
+      if (j >= run) v[0] = A[i];
+      else if (i >= run) v[0] = B[j];
+      else { const uint64_t x = A[i], y = B[j]; v[0] = x < y ? x : y; }
+    }
+  }
+  __syncthreads();
+  if (tid < n_pow2) keys[tid] = v[0];
+  __syncthreads();
+}
+
 template <int THREADS>
 __device__ __forceinline__ void block_bitonic_sort(uint64_t* keys, int n_pow2) {
   __syncthreads();                                         // keys were written by arbitrary threads before the call
   const int per = (n_pow2 + THREADS - 1) / THREADS;
-  if (per <= 1) block_bitonic_sort_regs<THREADS, 1>(keys, n_pow2);
+  if (per <= 1 && n_pow2 >= 256) block_merge_sort_e1<THREADS>(keys, n_pow2);
+  else if (per <= 1) block_bitonic_sort_regs<THREADS, 1>(keys, n_pow2);
   else if (per == 2) block_bitonic_sort_regs<THREADS, 2>(keys, n_pow2);
   else if (per == 4) block_bitonic_sort_regs<THREADS, 4>(keys, n_pow2);
   else if (per == 8) block_bitonic_sort_regs<THREADS, 8>(keys, n_pow2);
