@@ -25,6 +25,8 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     fdt = torch.bfloat16 if a.bf16 else torch.float16
+    if a.mode != "ab":
+        hip.roi_align_set_exact(a.mode == "exact")      # before the first launch: a counter run sees one kernel only
     path = FpnRegionPath(8, dev, feat_dtype=fdt, collect_top_n=a.top_n)
     inp = synthetic_batch(8, dev, seed=5000, feat_dtype=fdt, top_n=a.top_n, channels_last=a.channels_last)
     path.bind(*inp)
