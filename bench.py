@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--max-out", type=int, default=104, help="fixed detection rows per image through the mask branch: max_detections_per_img = 100 plus room for ties at the image threshold (the reference keeps them, result_utils.py:159-163; more ties than rows raise); 128 until round 3")
     ap.add_argument("--c4-pooled", type=int, default=7, help="cfg2: pooled size (7 as BASELINE names it; 14 = the reference's C4 default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-modes", action="store_true", help="skip the extra launches of the other RoIAlign modes (cfg2 fast / bf16 output, cfg5 exact): counter runs want ONE kernel per grid")
     ap.add_argument("--gather-always", action="store_true", help="run the per-step RCCL all-gather of the detections even at world size 1 (tests: exercises the N > 1 code path on one GPU; needs a launcher environment)")
     ap.add_argument("--cpu-images", type=int, default=8, help="images of the same workload run on the CPU oracle (timed + compared with the GPU); 2 when --gpus > 1")
     ap.add_argument("--cpu-procs", type=int, default=64, help="worker processes of the image-parallel CPU figure (capped by the host's cores)")
@@ -584,7 +585,7 @@ def main():
     k_ms = float(np.mean(k_all))
     alg_bytes = paths[0].box_roialign_bytes()
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    c4_extra = c4_modes(paths, iters, alg_bytes) if wl == "cfg2" else cfg5_modes(paths, iters, alg_bytes, dev) if contract else {}
+    c4_extra = {} if a.no_modes else c4_modes(paths, iters, alg_bytes) if wl == "cfg2" else cfg5_modes(paths, iters, alg_bytes, dev) if contract else {}
     harder = None
     if wl != "cfg2":                          # the same launch on the harder RoI population (a trained RPN looks like it)
         h_ms = harder_set_launch(paths[0], inputs[0][2], top_n, dev, max(5, iters // 2))
@@ -679,15 +680,17 @@ def main():
                                   "kernel); what bounds it is the adaptive-grid gather from LDS -- ~5 samples x 4 taps per bin and channel, "
                                   "formed with the reference's unfused multiply-adds -- i.e. LDS reads and VALU issue, not HBM (DESIGN 3.6)") if wl == "cfg2" else
                                  ("direct-gather kernel (roi_align_nhwc16.hip, DESIGN 3.1): every tap is a 16-byte load per lane straight from L1 / L2, "
-                                  "fabric traffic ~ the compulsory bytes; recorded counters of the 8000-RoI fp16 launch "
-                                  "(profiles/r04_z_nhwc16_boxhead_counters.json, not measured in this run): 91 % L1 hits, texture data path (TD) "
-                                  "83 % busy, VALU 59 % -- the floor of this formulation is the 64 B/clk/CU load-return path plus the reference's "
-                                  "unfused multiply-adds, not HBM") if a.channels_last else
-                                 "bound by the vector L1's window of outstanding line fills, not by HBM bandwidth and not by a CU pipe (DESIGN 3.1, "
-                                 "tools/r05/README.md 2, profiles/r05_a_*): the launch requests 2.3 x its algorithmic bytes as 128-byte L1 fills, a CU keeps "
-                                 "~64-77 of them in flight, half hit the XCD's L2 (~250 cycles) and half go to the Infinity Cache / HBM (~1150 cycles): "
-                                 "fills x mean latency / fills in flight reproduces the launch time of every variant measured; LDS array 55 % busy "
-                                 "(SQ_LDS_IDX_ACTIVE, bank conflicts included), VALU 43 %, waves parked 46 % (recorded counters, not measured in this run)"},
+                                  "fabric traffic ~ the compulsory bytes; in contract mode (16-bit maps) the taps of a bin that share a pixel are "
+                                  "requested once and pooled with one fused multiply-accumulate per element: recorded counters of the 16 000-RoI "
+                                  "launch (profiles/r06_z_cfg5_counters.json, not measured in this run): vector loads 6.8 M -> 4.2 M instructions, "
+                                  "VALU 66 -> 59 % of SIMD time, waves parked 46 -> 58 % -- a latency mix (3.4 waves per SIMD wait for ~9 loads, then "
+                                  "compute), no saturated unit; exact mode: texture data path + the reference's unfused multiply-adds") if a.channels_last else
+                                 "memory side of THIS formulation, not a CU pipe (DESIGN 3.1, tools/r06/README.md 1, profiles/r06_a_boxhead_three_way_replay.txt): "
+                                 "the launch replayed with only its staging loads left in (same workgroups, clusters, passes, addresses) takes 62 % of the "
+                                 "launch -- 2.67 GB of 128-byte L1 fills of which 1.22 GB come from the fabric at 5.3 TB/s; stores only 30 %, pooling from "
+                                 "LDS only 44 %; the shipped launch puts 1.63 GB (1.44 x algorithmic) on the fabric = 0.31 ms at that rate and runs at "
+                                 "1.1-1.2 x that; more loads in flight and an image-major order (Infinity-Cache-resident maps) were measured worse: what "
+                                 "is left is the 0.49 GB of fabric re-reads by neighbouring workgroups.  LDS array 55 % busy, VALU 43 % (recorded counters)"},
             "consistency": {"timed_region_s": round(dt, 4), "one_stream_ms_per_step": None if one_stream_ms is None else round(one_stream_ms, 4),
                             "gathered_equals_local": gathered_ok,
                             "gathered_equals_recomputed": recomputed_ok,

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 10 --warmup 2 --batch 8 --eager --inflight 1 --no-cpu-baseline --sustain-seconds 0 ${BENCH_ARGS:-}"   # BENCH_ARGS="--workload cfg5" etc.
+CMD="python bench.py --steps 10 --warmup 2 --batch 8 --eager --inflight 1 --no-cpu-baseline --no-modes --sustain-seconds 0 ${BENCH_ARGS:-}"   # BENCH_ARGS="--workload cfg5" etc.
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- $CMD > $OUT/stats.log 2>&1 < /dev/null
 # HBM-side traffic from the L2's fabric (EA) request counters, one counter group per run.  FETCH_SIZE itself is NOT used:
 # on gfx950 its expression prices every read request at 64 B (TCC_BUBBLE reads 0) while almost all requests are 128 B
