@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const uint64_t* __restri
 //   * lane (rg, cbl) ORs the words of the KEPT rows 4k + rg with a sign-extended bit field as the mask (3 instructions per
 //     row), the four row groups meet in LDS with one ds_or_b64;
 //   * no prefetch registers: the 17 LDS reads of a block are issued at the top of its iteration, under the resolve.
-constexpr int kReduceLdsThreads = 256;
+constexpr int kReduceLdsThreads = 1024;     // the copy wants loads in flight (round 6: 256 -> 1024 threads, 8 instead of 32 16-byte loads each); the walk is wave 0's
 
 __global__ __launch_bounds__(kReduceLdsThreads) void nms_reduce_lds_kernel(const uint64_t* __restrict__ mask,
                                                                            const uint64_t* __restrict__ diag_t,
@@ -328,21 +328,22 @@ __global__ __launch_bounds__(kReduceLdsThreads) void nms_reduce_lds_kernel(const
   uint64_t* Ml = reinterpret_cast<uint64_t*>(reduce_smem);
   uint64_t* DTl = Ml + (size_t)nrow_pad * ncb_stride;
   DTC_PT(0, s, 0);
-  removed[tid] = 0;
+  if (tid < 256) removed[tid] = 0;
   int n;
   {
     // 16-byte copies (ncb_stride is even and <= 16: the launcher checks) of the words on and right of the diagonal, every load
     // of a thread in flight at once -- and issued BEFORE the segment's count is known (the count is one more dependent global
     // round trip): rows of the workspace past the count hold stale words, they are replaced by zeros on the way into LDS, as
     // are the words left of the diagonal (never written by nms_mask)
-    constexpr int kPerThread = 32;             // 32 x 256 x 16 B = 128 KB
+    constexpr int kPerThread = 128 * 1024 / 16 / kReduceLdsThreads;      // x threads x 16 B = 128 KB
     const int ppr = ncb_stride >> 1;           // 16-byte pairs per row
     const int npair = nrow_pad * ppr;
     const ulonglong2* src = reinterpret_cast<const ulonglong2*>(Mg);
     ulonglong2* dst = reinterpret_cast<ulonglong2*>(Ml);
-    uint64_t dv[4];
+    constexpr int kDv = 1024 / kReduceLdsThreads;
+    uint64_t dv[kDv];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int i = tid + k * kReduceLdsThreads; dv[k] = i < n_stride ? DTg[i] : 0ull; }
+    for (int k = 0; k < kDv; k++) { const int i = tid + k * kReduceLdsThreads; dv[k] = i < n_stride ? DTg[i] : 0ull; }
     ulonglong2 v[kPerThread];
     // (row, pair) of element tid + k * 256, stepped without a division per element
     const int row0 = tid / ppr, pr0 = tid - row0 * ppr, drow = kReduceLdsThreads / ppr, dpr = kReduceLdsThreads - drow * ppr;
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(kReduceLdsThreads) void nms_reduce_lds_kernel(const
       if (pr >= ppr) { pr -= ppr; row++; }
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int i = tid + k * kReduceLdsThreads; if (i < nrow_pad) DTl[i] = i < n ? dv[k] : 0ull; }
+    for (int k = 0; k < kDv; k++) { const int i = tid + k * kReduceLdsThreads; if (i < nrow_pad) DTl[i] = i < n ? dv[k] : 0ull; }
   }
   const int ncb = (n + 63) >> 6;
   __syncthreads();

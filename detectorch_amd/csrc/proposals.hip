@@ -58,6 +58,7 @@ struct RpnParams {
   uint32_t* ticket;       // [S]             dynamic block index of rpn_decode (cleared with the histograms)
   uint32_t* blk_cnt;      // [S][decode blocks]  (count << 1) | ready, cleared with the histograms
   int dec_blocks;         // decode workgroups per segment
+  int resident;           // rpn_decode: the whole grid is co-resident -> launch-order block numbers instead of tickets
   float* out_boxes;     // [S][k_stride][4]
   float* out_scores;    // [S][k_stride]
   int32_t* out_counts;  // [S]
@@ -379,14 +380,24 @@ __global__ __launch_bounds__(kDecodeThreads) void rpn_decode_kernel(RpnParams p)
   const int seg = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = seg / p.n_levels, l = seg - b * p.n_levels;
   const RpnLevelDev& L = p.lv[l];
-  if (tid == 0) sh_blk = (int)atomicAdd(&p.ticket[seg], 1u);
-  __syncthreads();
-  const int blk = sh_blk;
-  // tickets past the block count: the workspace is shared with another in-flight call (include/detectorch_hip.h forbids it) or was
-  // not cleared for this launch -- leave instead of writing block counts out of bounds (uniform: after the barrier)
-  if (blk >= p.dec_blocks) return;
-  const int n_rank = p.n_rank[seg];
+  // Block number: a block waits for the blocks BEFORE it, so those must be running.  When the whole grid is co-resident (p.resident:
+  // the launcher checks grid <= 1024 workgroups of 256 threads on 256 CUs) the launch index serves and a dependent global round trip
+  // goes away; otherwise a run-time TICKET, so that a block only ever waits for blocks that were dispatched before it, whatever order
+  // the hardware dispatches workgroups in.
+  int blk = blockIdx.x;
+  if (!p.resident) {
+    if (tid == 0) sh_blk = (int)atomicAdd(&p.ticket[seg], 1u);
+    __syncthreads();
+    blk = sh_blk;
+    // tickets past the block count: the workspace is shared with another in-flight call (include/detectorch_hip.h forbids it) or was
+    // not cleared for this launch -- leave instead of writing block counts out of bounds (uniform: after the barrier)
+    if (blk >= p.dec_blocks) return;
+  }
   const uint64_t* sk = p.sorted_keys + (size_t)seg * p.k_stride;
+  // the rank's key is requested together with the segment's rank count (k < k_stride: a valid address whatever the count is)
+  const int k_spec = blk * kDecodeThreads + tid;
+  const uint64_t key_spec = k_spec < p.k_stride ? sk[k_spec] : 0ull;
+  const int n_rank = p.n_rank[seg];
   const float* sc = L.cls + (size_t)b * L.N;
   const float* dl = L.bbox + (size_t)b * L.N * 4;
   const int HW = L.H * L.W;
@@ -397,7 +408,7 @@ __global__ __launch_bounds__(kDecodeThreads) void rpn_decode_kernel(RpnParams p)
   float box[4] = {0.f, 0.f, 0.f, 0.f};
   float s = 0.f;
   if (k < n_rank) {
-    const uint64_t key = sk[k];
+    const uint64_t key = key_spec;
     const uint32_t n = desc_key_index(key);
     const int a = n % L.A, hw = n / L.A;
     const int h = hw / L.W, w = hw - h * L.W;
@@ -541,6 +552,7 @@ DTC_API int dtc_rpn_topk_decode(const dtc_rpn_level* levels, int n_levels, int b
   p.ticket = reinterpret_cast<uint32_t*>(w + plan.off_ticket);
   p.blk_cnt = reinterpret_cast<uint32_t*>(w + plan.off_blk);
   p.dec_blocks = plan.dec_blocks;
+  p.resident = (long long)plan.dec_blocks * plan.n_seg <= 1024 ? 1 : 0;     // 256 CUs hold >= 4 workgroups of 256 threads each
   p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_counts = out_counts;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // histograms + counters + tickets + block counts are contiguous at the start of the workspace
