@@ -79,8 +79,11 @@ template <int PASSES>
 __device__ __forceinline__ SelState load_state(const RpnParams& p, int seg, uint32_t K, uint32_t* sh) {
   SelState st; st.p0 = st.p1 = 0; st.krem = K;
   const uint32_t* H = p.hist + (size_t)seg * 2 * kHistBins;
-  if (PASSES >= 1) { select_digit(H, kHistBins, st.krem, sh); st.p0 = sh[0]; st.krem = sh[1]; __syncthreads(); }
-  if (PASSES >= 2) { select_digit(H + kHistBins, kHistBins, st.krem, sh); st.p1 = sh[0]; st.krem = sh[1]; __syncthreads(); }
+  DigitBins b0, b1;                            // both histograms are requested before the first selection consumes its bins
+  if (PASSES >= 1) load_digit_bins(H, kHistBins, b0);
+  if (PASSES >= 2) load_digit_bins(H + kHistBins, kHistBins, b1);
+  if (PASSES >= 1) { select_digit_loaded(b0, kHistBins, st.krem, sh); st.p0 = sh[0]; st.krem = sh[1]; __syncthreads(); }
+  if (PASSES >= 2) { select_digit_loaded(b1, kHistBins, st.krem, sh); st.p1 = sh[0]; st.krem = sh[1]; __syncthreads(); }
   return st;
 }
 
