@@ -33,6 +33,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "roi_align_common.h"
 
@@ -219,12 +220,17 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
       for (int u = 0; u < U; u++) v[u] = Piece4<TIn>::raw(srd, uoff[u] & 0x3fffffffu, soff);
     }
   };
-  auto commit = [&]() {
+  // Two instances behind ONE uniform branch: left as a condition inside the unrolled loop the compiler if-converted the shifted-piece
+  // selects of kStageVecUnaligned (P5's 42-column rows) into 9 v_cndmask per unit that EVERY commit executed -- 72 of the 104 vector
+  // instructions of a 16-bit commit, a fifth of a pass (round 6, from the ISA).
+  auto commit_as = [&](auto shifted_tag) {
+    constexpr bool SHIFTED = decltype(shifted_tag)::value;
+    if constexpr (SHIFTED) asm volatile("" ::: "memory");      // keeps the two instances apart (no if-conversion across it)
 #pragma unroll
     for (int u = 0; u < U; u++) {
       if constexpr (L16) {
         uint32_t w0 = v[u].x & 0xffffu, w1 = v[u].x >> 16, w2 = v[u].y & 0xffffu, w3 = v[u].y >> 16;
-        if (g.mode == kStageVecUnaligned) {
+        if constexpr (SHIFTED) {
           const uint32_t sft = uoff[u] >> 30;
           w0 = sft == 0 ? w0 : sft == 1 ? w1 : sft == 2 ? w2 : w3;
           w1 = sft == 0 ? w1 : sft == 1 ? w2 : w3;
@@ -234,7 +240,7 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
         d[0] = (TL)w0; d[4] = (TL)w1; d[8] = (TL)w2; d[12] = (TL)w3;
       } else {
         float4 w = v[u];
-        if (g.mode == kStageVecUnaligned) {     // shifted piece: pixel k of the piece is component k + shift of the load
+        if constexpr (SHIFTED) {                // shifted piece: pixel k of the piece is component k + shift of the load
           const uint32_t sft = uoff[u] >> 30;
           w.x = sft == 0 ? w.x : sft == 1 ? w.y : sft == 2 ? w.z : w.w;
           w.y = sft == 0 ? w.y : sft == 1 ? w.z : w.w;
@@ -244,6 +250,9 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
         d[0] = w.x; d[4] = w.y; d[8] = w.z; d[12] = w.w;
       }
     }
+  };
+  auto commit = [&]() {
+    if (g.mode == kStageVecUnaligned) commit_as(std::true_type{}); else commit_as(std::false_type{});
   };
   auto lds_val = [&](const TIn& x) -> TL {          // what the LDS image holds of a map element
     if constexpr (L16) return *reinterpret_cast<const uint16_t*>(&x); else return to_f32<TIn>(x);
