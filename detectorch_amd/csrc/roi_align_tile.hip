@@ -290,11 +290,16 @@ __device__ __forceinline__ void tile_passes(const RoiAlignParams& p, const dtc_f
     if (quad_ok && nch == 4 * nq) {
       const int n4 = nq * bins, total = g.count * n4;
       const float r4 = 1.0f / (float)n4;
+      // the RoI's output row for channel c0 as ONE 64-bit element offset, formed once per RoI in phase A (TileRoi::x0 / x1 in LDS):
+      // the store's address is that + a uniform term + 4 e -- (r * channels + c0 + cs) * bins in 64-bit integer multiplies per 16-byte
+      // store was six quarter-rate instructions, a quarter of a pass's vector time on 16-bit maps (round 6, from the ISA)
+      const int cs_off = cs * bins;
       for (int idx = tid; idx < total; idx += NT) {
         const int k = (int)(((float)idx + 0.5f) * r4);            // exact for idx < 2^13
-        const int e = idx - k * n4;
+        const int e = idx - __mul24(k, n4);
         const float4 val = reinterpret_cast<const float4*>(slab)[idx];
-        store_quad<TOut>(out + ((size_t)troi[g.first + k].r * p.channels + c0 + cs) * bins + 4 * e, val);
+        const uint64_t ob = *reinterpret_cast<const uint64_t*>(&troi[g.first + k].x0);
+        store_quad<TOut>(out + (ob + (uint64_t)(uint32_t)(cs_off + 4 * e)), val);
       }
     } else {
       const int per = nch * bins, total = g.count * per;
@@ -541,7 +546,11 @@ __global__ __launch_bounds__(NT, (TileBounds<TIn, NT>::kWaves)) void roi_align_f
         t.x1 = make_axis(hd.sw, hd.bin_w, p.pooled_w - 1, 1, 2, W).hi;
       }
     }
-    if (tid < K) troi[tid] = t;
+    if (tid < K) {
+      troi[tid] = t;
+      // (x0 / x1 are read from the REGISTER copy below, never from LDS: their LDS words carry the RoI's output offset, see store_slab)
+      *reinterpret_cast<uint64_t*>(&troi[tid].x0) = ((uint64_t)(uint32_t)t.r * (uint64_t)p.channels + (uint64_t)c0) * (uint64_t)(p.pooled_h * p.pooled_w);
+    }
     auto bc = [](int v, int k) { return __builtin_amdgcn_readlane(v, k); };     // k: uniform lane index
     int ng = 0, k = 0;
     while (k < K) {
