@@ -404,6 +404,7 @@ class OverlappedRegionPath:
         self.graph = None
         p0 = self.sub[0]
         self.max_out, self.top_n, self.pad_h, self.pad_w = p0.max_out, p0.top_n, p0.pad_h, p0.pad_w
+        self.box_p, self.mask_p, self.C, self.feat_dtype = p0.box_p, p0.mask_p, p0.C, p0.feat_dtype
 
     def bind(self, rpn_cls, rpn_bbox, feats, cls_score, bbox_pred, masks, scaling_factor, im_size):
         k = self.B // self.n
@@ -439,6 +440,10 @@ class OverlappedRegionPath:
     @property
     def dets(self):
         return torch.cat([p.dets for p in self.sub], 0)
+
+    @property
+    def box_feats(self):
+        return torch.cat([p.box_feats for p in self.sub], 0)
 
     @property
     def det_count(self):

@@ -46,6 +46,18 @@ def test_vs_oracle_sizes(hip, oracle, n, thr):
     assert np.array_equal(keep, oracle.nms(d, thr))
 
 
+@pytest.mark.parametrize("n", [127, 128, 200, 255, 256, 257, 300, 511, 512, 513, 777, 1023, 1024, 1025, 1500, 2047, 2048, 2049])
+def test_sort_size_sweep_through_the_drop_in(hip, oracle, n):
+    """dtc_nms = segment sort (score desc, index asc) + mask + reduce + a second sort of the kept indices.  Sizes on both sides of every
+    branch of block_sort.h (round 6): <= 128 keys and more than one key per thread on the bitonic network with DPP / ds_swizzle steps,
+    256 <= n_pow2 <= 1024 on the wave-local sort + merge-path rounds; runs of EQUAL scores (quantised to 1/32) so that the index half of
+    the key decides -- keep indices bit-equal to the oracle."""
+    d = _dets(9000 + n, n)
+    d[:, 4] = np.round(d[:, 4] * 32) / 32
+    keep = hip.nms(torch.from_numpy(d).cuda(), 0.5).cpu().numpy()
+    assert np.array_equal(keep, oracle.nms(d, 0.5))
+
+
 def test_heavy_overlap_and_ties(hip, oracle):
     # dense cluster: long suppression chains inside one 64-row block
     rs = synth.rng(7, 1234)
