@@ -111,9 +111,9 @@ __device__ __forceinline__ N16Rec n16_merge_axis(const N16Tab& e0, const N16Tab&
       if (j < k && live[k] && live[j] && off[k] == off[j]) { w[j] += w[k]; live[k] = false; }
     }
   }
-  N16Rec r;
+  N16Rec r;      // a folded entry keeps its (valid, duplicate) offset and gets weight 0: it may be read and accumulated unpredicated
 #pragma unroll
-  for (int k = 0; k < 4; k++) { r.off[k] = off[k] | (k && live[k] ? 1u : 0u); r.w[k] = w[k]; }
+  for (int k = 0; k < 4; k++) { r.off[k] = off[k] | (k && live[k] ? 1u : 0u); r.w[k] = live[k] ? w[k] : 0.f; }
   return r;
 }
 
@@ -123,27 +123,48 @@ __device__ __forceinline__ void n16_pool_bin_shared(const N16Rec& ya, const N16R
   uint32_t oy[4], ox[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) { ly[k] = k == 0 || (ya.off[k] & 1u); lx[k] = k == 0 || (xa.off[k] & 1u); oy[k] = ya.off[k] & ~1u; ox[k] = xa.off[k] & ~1u; }
-  uint4 t[16];              // a lane's t[4 i + j] is defined (and read) only where its entries i and j are both live
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (ly[i] && lx[j]) t[4 * i + j] = ld(oy[i], ox[j]);                      // only the lanes that hold this pixel request it
-  __builtin_amdgcn_sched_barrier(0);
   f32x2 a[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) a[k] = f32x2{0.f, 0.f};
+  // Wavefronts whose bins are all under 2 px (no lane holds entry 2 of either axis: the usual case on P2) take STRAIGHT-LINE code over
+  // the nine pixels {0, 1, 3} x {0, 1, 3}: a lane whose entry 1 or 3 is folded re-reads a pixel it holds anyway (an L1 hit) with
+  // weight 0 -- a few more loads than the masked form below, none of its 32 exec-mask blocks.
+  if (__ballot(ly[2] || lx[2]) == 0ull) {
+    uint4 t9[9];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 3; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (ly[i] && lx[j]) {                                                     // (a wavefront without such a lane skips the block)
-        const float w = ya.w[i] * xa.w[j];
-        const uint32_t* u = reinterpret_cast<const uint32_t*>(&t[4 * i + j]);
+      for (int j = 0; j < 3; j++) t9[3 * i + j] = ld(oy[i == 2 ? 3 : i], ox[j == 2 ? 3 : j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const float w = ya.w[i == 2 ? 3 : i] * xa.w[j == 2 ? 3 : j];
+        const uint32_t* u = reinterpret_cast<const uint32_t*>(&t9[3 * i + j]);
 #pragma unroll
         for (int k = 0; k < 4; k++) fma_pair16<TIn>(a[k], u[k], w);
       }
-    }
+  } else {
+    uint4 t[16];              // a lane's t[4 i + j] is defined (and read) only where its entries i and j are both live
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (ly[i] && lx[j]) t[4 * i + j] = ld(oy[i], ox[j]);                      // only the lanes that hold this pixel request it
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (ly[i] && lx[j]) {                                                     // (a wavefront without such a lane skips the block)
+          const float w = ya.w[i] * xa.w[j];
+          const uint32_t* u = reinterpret_cast<const uint32_t*>(&t[4 * i + j]);
+#pragma unroll
+          for (int k = 0; k < 4; k++) fma_pair16<TIn>(a[k], u[k], w);
+        }
+      }
+  }
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const f32x2 o = a[k] * 0.25f;
