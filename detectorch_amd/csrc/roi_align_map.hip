@@ -194,6 +194,24 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
   const int r_end = min(p.n_rois, (seg + 1) * seg_len);
   TOut* out = reinterpret_cast<TOut*>(p.out);
   const float rpw = __frcp_rn((float)p.pooled_w);
+  // lane <-> bin.  A ds_read_b128 is served in four FIXED groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same
+  // + 32 -- each conflict-free when its lanes hit 16 distinct 16-byte slots modulo 256 B.  bin = lane puts three or four bin rows into
+  // a group; when the bins fit (pooled_w <= 8, pooled_h <= 8: the 7 x 7 box head) every group takes TWO whole bin rows instead --
+  // fewer distinct map rows per group: simulated on the cfg2 proposals 8.25 -> 7.13 LDS cycles per tap read (4 = conflict-free),
+  // tools/r06/lds_lane_maps.py.  The output slab is indexed by bin, so nothing else changes.
+  const bool rows2 = p.pooled_w <= 8 && p.pooled_h <= 8;
+  int pm_bin = 0;
+  bool pm_on = false;
+  {
+    const int h = lane & 31;
+    const bool t0 = h < 4 || (h >= 12 && h < 16) || (h >= 20 && h < 28);
+    const int pos = t0 ? (h < 4 ? h : h < 16 ? h - 8 : h - 12) : (h < 12 ? h - 4 : h < 20 ? h - 8 : h - 16);
+    const int grp = (lane >> 5) * 2 + (t0 ? 0 : 1);
+    const int hi = pos >= p.pooled_w ? 1 : 0;
+    const int prow = 2 * grp + hi, pcol = pos - hi * p.pooled_w;
+    pm_on = prow < p.pooled_h && pcol < p.pooled_w;
+    pm_bin = pm_on ? prow * p.pooled_w + pcol : min(2 * grp, p.pooled_h - 1) * p.pooled_w;      // idle lanes repeat the first bin of their OWN group (a broadcast)
+  }
   if (tid == 0) s_next = seg * seg_len;
   __syncthreads();
   int cur = -1;                               // image whose map is staged (uniform)
@@ -270,28 +288,44 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
       }
 #pragma unroll 1
       for (int b0 = 0; b0 < bins; b0 += 64) {
-        const int bin = min(b0 + lane, bins - 1);        // lanes past the last bin repeat it (uniform control flow), never stored
-        const bool on = b0 + lane < bins;
+        const int bin = rows2 ? pm_bin : min(b0 + lane, bins - 1);        // lanes past the last bin repeat one (uniform control flow), never stored
+        const bool on = rows2 ? pm_on : b0 + lane < bins;
         const int ph = (int)(((float)bin + 0.5f) * rpw), pw = bin - ph * p.pooled_w;     // bin / pooled_w, exact (bins < 2^16)
         mf32x2 acc[NQ][2];
 #pragma unroll
         for (int q = 0; q < NQ; q++) { acc[q][0] = mf32x2{0.f, 0.f}; acc[q][1] = mf32x2{0.f, 0.f}; }
         if (merged) {
-          // fast mode: one tap per (row, column) of the bin's footprint, weight Wy * Wx (see map_prep_kernel)
+          // fast mode: one tap per (row, column) of the bin's footprint, weight Wy * Wx (see map_prep_kernel).  The column entries of
+          // FOUR taps are fetched once (registers) and reused by every footprint row -- two wave shuffles per four taps instead of per
+          // tap -- and a tap is one fused multiply-add per channel pair (contract mode has no operation order to keep): per tap and
+          // channel-quad pair 2 ds_read_b128 + 4 v_pk_fma_f32 where round 5 issued 2 + 2 shuffles and 4 v_pk_mul + 4 v_pk_add.
           const int KY = gh + 1, KX = gw + 1;
-#pragma unroll 1
-          for (int iy = 0; iy < KY; iy++) {
-            const int sy = ph * KY + iy;
-            const int yo = __shfl(ey_lo, sy, 64); const float wy = __shfl(ey.h, sy, 64);
-#pragma unroll 1
-            for (int ix = 0; ix < KX; ix++) {
-              const int sx = pw * KX + ix;
-              const int xo = __shfl(ex_lo, sx, 64); const float w = wy * __shfl(ex.h, sx, 64);
+          auto tap = [&](const char* m, int xo, float w) {
+            const mf32x2 wv = {w, w};
 #pragma unroll
-              for (int q = 0; q < NQ; q++) {
-                const mf32x4 v = *reinterpret_cast<const mf32x4*>(__builtin_assume_aligned(map + q * plane_bytes + yo + xo, 16));
-                acc[q][0] += w * v.lo; acc[q][1] += w * v.hi;
-              }
+            for (int q = 0; q < NQ; q++) {
+              const mf32x4 v = *reinterpret_cast<const mf32x4*>(__builtin_assume_aligned(m + q * plane_bytes + xo, 16));
+              acc[q][0] = __builtin_elementwise_fma(wv, v.lo, acc[q][0]); acc[q][1] = __builtin_elementwise_fma(wv, v.hi, acc[q][1]);
+            }
+          };
+#pragma unroll 1
+          for (int x0 = 0; x0 < KX; x0 += 4) {
+            const int nk = min(4, KX - x0);                       // uniform
+            int xo[4]; float wx[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const int sx = pw * KX + min(x0 + k, KX - 1);
+              xo[k] = __shfl(ex_lo, sx, 64); wx[k] = __shfl(ex.h, sx, 64);
+            }
+#pragma unroll 1
+            for (int iy = 0; iy < KY; iy++) {
+              const int sy = ph * KY + iy;
+              const int yo = __shfl(ey_lo, sy, 64); const float wy = __shfl(ey.h, sy, 64);
+              const char* m = map + yo;
+              tap(m, xo[0], wy * wx[0]);
+              if (nk > 1) tap(m, xo[1], wy * wx[1]);
+              if (nk > 2) tap(m, xo[2], wy * wx[2]);
+              if (nk > 3) tap(m, xo[3], wy * wx[3]);
             }
           }
         } else
