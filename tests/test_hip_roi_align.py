@@ -188,17 +188,20 @@ def _c4_rois(rs, n, im_h=800, im_w=1333):
     return np.stack([x1, y1, x2, y2], 1).astype(np.float32)
 
 
-@pytest.mark.parametrize("case", ["p7_slab", "p14_direct", "tail_c50", "fp16", "shuffled", "sr3", "col4"])
+@pytest.mark.parametrize("case", ["p7_slab", "p14_direct", "tail_c50", "fp16", "shuffled", "sr3", "col4", "rect_5x8", "rect_8x6", "rect_9x4"])
 def test_map_stationary_kernel_vs_oracle(hip, oracle, case):
     """The single-level (C4) kernel roi_align_fwd_map: whole map of 8 channels in LDS, one RoI per wavefront.  Packed
     descriptors as dtc_fpn_collect_distribute emits them (image-major, with padding rows), adaptive sampling; 7x7 bins (LDS
     slab + 16-byte stores), 14x14 bins (direct stores, 4 bin chunks per RoI), a channel count that is not a multiple of 4
     (single quads, clamped tail), fp16 features, a NOT image-major order (every change of image re-stages the map: slow,
-    still exact), a fixed non-2 sampling ratio, and the 4-column (single image) plain entry."""
+    still exact), a fixed non-2 sampling ratio, the 4-column (single image) plain entry, and rectangular bin grids (round 6: the
+    lane <-> bin assignment of 7 x 7-like grids puts two whole bin rows into each ds_read_b128 lane group)."""
     rs = synth.rng(8, 77)
     B, H, W = 3, 50, 84
     C = 50 if case == "tail_c50" else 128
     ph = pw = 14 if case == "p14_direct" else 7
+    if case.startswith("rect_"):      # rectangular bins: both sides of the two-bin-rows-per-lane-group assignment (pooled_h, pooled_w <= 8) and past it
+        ph, pw = (int(v) for v in case[5:].split("x"))
     sr = 3 if case == "sr3" else 0
     n = 700 if C == 128 else 1500           # R * C >= 64 K: below that the dispatcher keeps the RoI-stationary kernel
     feat = synth.make_features(rs, (B, C, H, W))
