@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void map_prep_kernel(RoiAlignParams p, MapPrep
     merged = __ballot(!fits) == 0ull;
   }
   if (merged) {
-    T->y[lane] = map_merged_entry<true>(hd, lane, gh, p.pooled_h, H, pitch * 16);
+    MapAxis my = map_merged_entry<true>(hd, lane, gh, p.pooled_h, H, pitch * 16);
+    my.h = my.h * fdiv(1.0f, hd.count);                  // the mean over the gh x gw samples, folded into the row weights
+    T->y[lane] = my;
     T->x[lane] = map_merged_entry<false>(hd, lane, gw, p.pooled_w, W, 16);
   } else if (!padrow) {
     // entry e = (bin e / g, sample e % g) by lane e: (lane + .5) * (1 / g) truncated is exact (>= .5 / g away from an integer)
@@ -358,15 +360,23 @@ __global__ __launch_bounds__(kMapThreads) void roi_align_fwd_map(RoiAlignParams 
         for (int q = 0; q < NQ; q++) {
           res[4 * q + 0] = acc[q][0].x; res[4 * q + 1] = acc[q][0].y; res[4 * q + 2] = acc[q][1].x; res[4 * q + 3] = acc[q][1].y;
         }
+        // :216  output_val /= count.  count = gh * gw is a small integer: a power of two -> the product with its reciprocal is
+        // the quotient; otherwise float(double(x) * double(1 / count)) IS the correctly rounded float32 quotient -- x / count
+        // can never sit within 2^-33 (relative) of a rounding boundary of float32 (a 25-bit midpoint times an integer < 2^8
+        // is not a 24-bit number), while the double product is within 2^-52 of it -- at 3 instructions instead of the ~12 of
+        // an IEEE division (eight of them per RoI and channel group).  The argument needs count < 2^8: a very large RoI -- gh * gw >=
+        // 256 samples per bin -- takes the IEEE division.  ONE uniform branch around the channel loop (written per channel the
+        // compiler emitted a chain of branches per channel); fast mode: 1 / count is folded into the row weights by map_prep_kernel.
+        if (merged) {
+        } else if (inv_count != 0.f) {
 #pragma unroll
-        for (int c = 0; c < CG; c++) {
-          // :216  output_val /= count.  count = gh * gw is a small integer: a power of two -> the product with its reciprocal is
-          // the quotient; otherwise float(double(x) * double(1 / count)) IS the correctly rounded float32 quotient -- x / count
-          // can never sit within 2^-33 (relative) of a rounding boundary of float32 (a 25-bit midpoint times an integer < 2^8
-          // is not a 24-bit number), while the double product is within 2^-52 of it -- at 3 instructions instead of the ~12 of
-          // an IEEE division (eight of them per RoI and channel group).
-          // (the argument needs count < 2^8: a very large RoI -- gh * gw >= 256 samples per bin -- takes the IEEE division; uniform branch)
-          res[c] = inv_count != 0.f ? res[c] * inv_count : count < 256.f ? (float)((double)res[c] * rcp_count) : fdiv(res[c], count);
+          for (int c = 0; c < CG; c++) res[c] = res[c] * inv_count;
+        } else if (count < 256.f) {
+#pragma unroll
+          for (int c = 0; c < CG; c++) res[c] = (float)((double)res[c] * rcp_count);
+        } else {
+#pragma unroll
+          for (int c = 0; c < CG; c++) res[c] = fdiv(res[c], count);
         }
         if (use_slab) {
           // bins <= 64, whole channel quads: [CG][bins] is ONE contiguous run of the output -> wave-private slab, 16-byte stores
