@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--max-out", type=int, default=104, help="fixed detection rows per image through the mask branch: max_detections_per_img = 100 plus room for ties at the image threshold (the reference keeps them, result_utils.py:159-163; more ties than rows raise); 128 until round 3")
     ap.add_argument("--c4-pooled", type=int, default=7, help="cfg2: pooled size (7 as BASELINE names it; 14 = the reference's C4 default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-modes", action="store_true", help="skip the extra launches of the other RoIAlign modes (cfg2 fast / bf16 output, cfg5 exact): counter runs want ONE kernel per grid")
+    ap.add_argument("--no-modes", action="store_true", help="skip the extra launches of the other RoIAlign modes (cfg2 fast / bf16 output, cfg5 exact) and of the harder RoI set: counter and kernel-trace runs want ONE kernel and ONE RoI population per grid")
     ap.add_argument("--gather-always", action="store_true", help="run the per-step RCCL all-gather of the detections even at world size 1 (tests: exercises the N > 1 code path on one GPU; needs a launcher environment)")
     ap.add_argument("--cpu-images", type=int, default=8, help="images of the same workload run on the CPU oracle (timed + compared with the GPU); 2 when --gpus > 1")
     ap.add_argument("--cpu-procs", type=int, default=64, help="worker processes of the image-parallel CPU figure (capped by the host's cores)")
@@ -587,7 +587,8 @@ def main():
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     c4_extra = {} if a.no_modes else c4_modes(paths, iters, alg_bytes) if wl == "cfg2" else cfg5_modes(paths, iters, alg_bytes, dev) if contract else {}
     harder = None
-    if wl != "cfg2":                          # the same launch on the harder RoI population (a trained RPN looks like it)
+    if wl != "cfg2" and not a.no_modes:       # the same launch on the harder RoI population (a trained RPN looks like it);
+                                              # not in counter / kernel-trace runs: they average per grid, and this leg launches the same grid
         h_ms = harder_set_launch(paths[0], inputs[0][2], top_n, dev, max(5, iters // 2))
         harder = {"launch_ms": round(h_ms, 4), "frac": round(alg_bytes / (h_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                   "rois": "log-uniform sides 16-600 px, FPN level by area, sorted (image, level, 32-row band, x): tools/bench_roialign.py --sort"}

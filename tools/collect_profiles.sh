@@ -24,6 +24,15 @@ with open(out + "/kernel_stats.csv", "w", newline="") as f:
     w.writerow(rows[0])
     for r in rows[1:]:
         w.writerow([r[0] if len(r[0]) <= 110 else r[0][:107] + "..."] + r[1:])
+# RoIAlign launches of the kernel trace by (kernel, grid): the box-head and the mask-head launch share a kernel, the --stats average mixes them
+by = collections.defaultdict(list)
+for r in csv.DictReader(open(out + "/stats_kernel_trace.csv")):
+    if "roi_align" in r["Kernel_Name"]:
+        by[(r["Kernel_Name"].split("(")[0][-70:], int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+with open(out + "/launches_by_grid.txt", "w") as f:
+    for (k, g), v in sorted(by.items(), key=lambda kv: -kv[0][1]):
+        v = sorted(v)
+        f.write("%-72s grid %8d  launches %3d  avg %8.1f us  median %8.1f  min %8.1f\n" % (k, g, len(v), sum(v) / len(v) / 1e3, v[len(v) // 2] / 1e3, v[0] / 1e3))
 raw = collections.defaultdict(lambda: collections.defaultdict(list))      # grid -> counter -> values
 for name in ("fetch", "write"):
     for r in csv.DictReader(open(out + "/%s_counter_collection.csv" % name)):

@@ -11,6 +11,9 @@ for w in cfg3 cfg3nhwc cfg5 cfg5nchw cfg2; do
   cp $G/${T}_$w/kernel_stats.csv profiles/r06_z_bench_${w}_eager_kernel_stats.csv
   cp $G/${T}_$w/traffic.json profiles/r06_z_roialign_${w}_pmc_raw.json
 done
+( echo "# rocprofv3 --kernel-trace of the bench command per workload (tools/collect_profiles.sh): RoIAlign launches by kernel and grid size"
+  echo "# (the box-head and the mask-head launch share a kernel: the --stats average in *_kernel_stats.csv mixes them)"
+  for w in cfg3 cfg3nhwc cfg5 cfg5nchw cfg2; do sed "s/^/$w  /" $G/${T}_$w/launches_by_grid.txt; done ) > profiles/r06_z_roialign_launches_by_grid.txt
 cp $G/$T/roialign_traffic.json profiles/roialign_traffic.json      # the table bench.py reads (entries stamped with the kernel-source hash)
 cp $G/${T}_fills_nchw/l1_fills.json profiles/r06_z_boxhead_l1_fill_counters_nchw.json
 cp $G/${T}_fills_nhwc/l1_fills.json profiles/r06_z_boxhead_l1_fill_counters_nhwc.json
