@@ -155,8 +155,60 @@ def c4_sim():
                             tot += cost(addrs); n += 1
             print("  pitch %d  %-40s %.2f cycles / ds_read_b128" % (pitch, nm, tot / n))
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "mask"):
     if len(sys.argv) > 1 and sys.argv[1] == "c4": c4_sim()
     else:
         fpn_cluster_sim("kernel")
         for sk in (1, 3, 5, 7): fpn_cluster_sim(sk)
+
+
+def mask_head_sim():
+    """14 x 14 bins, one RoI per workgroup (the mask head of the cluster kernel): tid = bin against one bin ROW per 16-lane group."""
+    rs = np.random.RandomState(5)
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42)]
+    res = {"tid = bin [kernel]": [0, 0], "one bin row per lane group (14 of 16 lanes)": [0, 0]}
+    for _ in range(150):
+        side = np.exp(rs.uniform(np.log(40), np.log(700))); ar = np.exp(rs.uniform(-0.6, 0.6))
+        w, h = side * np.sqrt(ar), side / np.sqrt(ar)
+        lvl = int(np.clip(np.floor(4 + np.log2(np.sqrt(w * h) / 224 + 1e-6)), 2, 5)) - 2
+        H, W = shapes[lvl]; s = F(1.0 / (4 << lvl))
+        cx, cy = rs.uniform(w / 2, 1333 - w / 2), rs.uniform(h / 2, 800 - h / 2)
+        x1, y1, x2, y2 = cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2
+        sw, sh = F(x1) * s, F(y1) * s
+        rw = max(F(F(x2) * s - sw), F(1)); rh = max(F(F(y2) * s - sh), F(1))
+        bh, bw = F(rh / F(14)), F(rw / F(14))
+        ys = [[axis(sh, bh, p, i, 2, H) for i in range(2)] for p in range(14)]
+        xs = [[axis(sw, bw, p, i, 2, W) for i in range(2)] for p in range(14)]
+        x0, x1i, y0 = xs[0][0][0], xs[13][1][1], ys[0][0][0]
+        x0a = x0 & ~3; tw = 4 * ((x1i >> 2) - (x0 >> 2) + 1)
+        f = lambda row, col: (lambda px: px + (px >> 3))((row - y0) * tw + (col - x0a))
+        maps = {}
+        maps["tid = bin [kernel]"] = [[(b // 14, b % 14) if b < 196 else None for b in range(wv * 64, wv * 64 + 64)] for wv in range(4)]
+        m2 = []
+        for wv in range(4):
+            lanes = [None] * 64
+            for gi, g in enumerate(GROUPS):
+                row = wv * 4 + gi
+                for pos, ln in enumerate(g):
+                    if row < 14 and pos < 14: lanes[ln] = (row, pos)
+            m2.append(lanes)
+        maps["one bin row per lane group (14 of 16 lanes)"] = m2
+        for nm, waves in maps.items():
+            for wave in waves:
+                if all(e is None for e in wave): continue
+                for iy in range(2):
+                    for ix in range(2):
+                        for tap in range(4):
+                            addrs = [None] * 64
+                            for ln, e in enumerate(wave):
+                                if e is None: continue
+                                ph, pw = e
+                                ylo, yhi = ys[ph][iy]; xlo, xhi = xs[pw][ix]
+                                addrs[ln] = f((ylo, ylo, yhi, yhi)[tap], (xlo, xhi, xlo, xhi)[tap])
+                            res[nm][0] += cost(addrs); res[nm][1] += 1
+    for nm, (c, n) in res.items():
+        print("mask head 14 x 14: %-46s %.2f LDS cycles per ds_read_b128 wave-instruction (%d instructions per RoI and tap set)" % (nm, c / n, n // 150))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "mask":
+    mask_head_sim()
